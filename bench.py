@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: by default BASELINE.json configs[2], the roofline run
+(Radix2Fft.forwardComplex semantics, fp32 planar complex, N=4096, batch=65536
+per GPU).  For N>1 the driver launches one process per GPU (torch.distributed.run);
+the batch is split by rank with no data-path collective (weak scaling: 65,536
+transforms per GPU, configs[4] at N=8), and the timed region is bracketed by a
+barrier + synchronize with the MAX over ranks taken.  Rank 0 prints ONE JSON line.
+
+Other workloads (parity-checked elsewhere; here for DESIGN.md's numbers):
+  --workload spectrum16k   configs[3]: fused Hann+FFT+one-sided amplitude, N=16384,
+                           streamed in chunks of --chunk frames
+  --workload real4096      Radix2Fft.forward semantics (real in, 12 B/sample)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured float4 copy
+
+
+def synth_batch(batch: int, n: int, device, seed: int = 1337, complex_noise: bool = True):
+    """SURVEY 8(d) config 3 input: first half sines A*sin(2*pi*k*i/N + phi) with
+    A~U[0.5,2], integer k~U{1..N/2-1}, phi~U[0,2pi), imag = 0; second half complex
+    Gaussian noise.  Counter-based (Philox) torch generator, seed 1337 (+rank)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    half = batch // 2
+    re = torch.empty((batch, n), dtype=torch.float32, device=device)
+    im = torch.zeros((batch, n), dtype=torch.float32, device=device)
+    idx = torch.arange(n, dtype=torch.float32, device=device)
+    step = 4096
+    for s in range(0, half, step):
+        e = min(half, s + step)
+        a = torch.rand((e - s, 1), generator=g, device=device) * 1.5 + 0.5
+        k = torch.randint(1, max(2, n // 2), (e - s, 1), generator=g, device=device).to(torch.float32)
+        phi = torch.rand((e - s, 1), generator=g, device=device) * (2 * np.pi)
+        re[s:e] = a * torch.sin((2 * np.pi / n) * k * idx + phi)
+    re[half:].normal_(generator=g)
+    if complex_noise:
+        im[half:].normal_(generator=g)
+    return re, im
+
+
+def cpu_baseline(re_rows: np.ndarray, im_rows, n: int, target_s: float = 12.0):
+    """The oracle (f64 scalar restatement of src/core/fft.ts, 1 thread) timed on a
+    bounded sample of the same workload: the first rows of the GPU batch, looped
+    with plan and `out` reused and a checksum guard (bench/run.ts:13-26)."""
+    import oracle
+    plan = oracle.Plan(n)
+    rows = re_rows.shape[0]
+    sec, _ = plan.time_forward(re_rows[:64], None if im_rows is None else im_rows[:64], reps=1)  # warm-up
+    sec, _ = plan.time_forward(re_rows[:256], None if im_rows is None else im_rows[:256], reps=1)
+    per = sec / 256
+    reps = max(1, int(target_s / (per * rows)))
+    sec, chk = plan.time_forward(re_rows, im_rows, reps=reps)
+    done = rows * reps
+    return {
+        "value": done * n / sec / 1e9,
+        "unit": "GSample/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{done} transforms of N={n} ({rows} distinct rows of the GPU batch x {reps} passes), "
+                  f"{sec:.1f} s, f64 scalar C -O2, host has {os.cpu_count()} cpus",
+        "transforms_per_s": done / sec,
+        "checksum": chk,
+    }
+
+
+def traffic_from_profile(kernel_substr: str):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes, corrected as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950; units of KiB).  The
+    numbers are written by tools/pmc_summary.py into profiles/traffic.json."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        d = json.load(open(p))
+        for k, v in d.items():
+            if kernel_substr in k:
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+    return None
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "spectrum16k"])
+    ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
+    ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of the output slabs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the pdsp engine has no CPU fallback)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from pragma_dsp_amd.batch import BatchedFft
+
+    if args.workload == "spectrum16k":
+        n, per_gpu = 16384, args.batch or (1 << 20)
+    else:
+        n, per_gpu = 4096, args.batch or 65536
+    plan = BatchedFft(n, dev)
+    stream = torch.cuda.current_stream(dev)
+
+    if args.workload == "fft4096":
+        re, im = synth_batch(per_gpu, n, dev, seed=1337 + rank)
+        ore, oim = torch.empty_like(re), torch.empty_like(im)
+        launches_per_step = 1
+        bytes_per_launch = 16 * per_gpu * n  # 8 B read + 8 B written per sample
+        kernel_name = "LoadComplex"
+
+        def step():
+            plan.forward(re, im, out=(ore, oim))
+    elif args.workload == "real4096":
+        re, _ = synth_batch(per_gpu, n, dev, seed=1337 + rank, complex_noise=False)
+        im = None
+        ore, oim = torch.empty_like(re), torch.empty_like(re)
+        launches_per_step = 1
+        bytes_per_launch = 12 * per_gpu * n
+        kernel_name = "LoadReal"
+
+        def step():
+            plan.forward(re, None, out=(ore, oim))
+    else:
+        chunk = min(args.chunk, per_gpu)
+        assert per_gpu % chunk == 0
+        re, _ = synth_batch(chunk, n, dev, seed=1337 + rank, complex_noise=False)
+        im = None
+        bins = n // 2 + 1
+        amp = torch.empty((chunk, bins), dtype=torch.float32, device=dev)
+        launches_per_step = per_gpu // chunk
+        bytes_per_launch = (4 * n + 4 * bins) * chunk  # 98,308 B per frame
+        kernel_name = "LoadFrameWindowed"
+        plan.window("hann")
+
+        def step():
+            # the stream of 2^20 frames is generated on-device; each chunk of frames is
+            # consumed from the same HBM-resident buffer (64 GiB would not change the kernel)
+            for _ in range(launches_per_step):
+                plan.spectrum(re, "hann", "one", out=amp)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record(stream)
+    for i in range(args.steps):
+        step()
+        evs[i + 1].record(stream)  # same stream the kernels are launched on
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    gather = None
+    if args.gather and world > 1 and args.workload != "spectrum16k":
+        import torch.distributed as dist
+        slab = torch.stack([ore, oim])  # [2][B][N] local output slab
+        full = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=dev)
+        dist.all_gather_into_tensor(full, slab)  # warm-up (communicator setup)
+        barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(full, slab)
+        torch.cuda.synchronize(dev)
+        gsec = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
+        dist.all_reduce(gsec, op=dist.ReduceOp.MAX)
+        gather = {"ms": float(gsec.item()) * 1e3, "bytes_per_rank": slab.numel() * 4,
+                  "GBps_in_per_gpu": slab.numel() * 4 * (world - 1) / float(gsec.item()) / 1e9}
+
+    if rank == 0:
+        samples_per_step = per_gpu * n * world
+        value = samples_per_step * args.steps / elapsed / 1e9
+        launch_ms = float(np.mean(step_ms)) / launches_per_step
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "batched 1D FFT GSample/s at N=4096 batch=65536; achieved HBM GB/s vs peak"
+            if args.workload == "fft4096" else f"GSample/s ({args.workload})",
+            "value": value,
+            "unit": "GSample/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": {"fft4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex (configs[2])",
+                                    "real4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forward fp32 real input",
+                                    "spectrum16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude (configs[3])"}[args.workload],
+                       "n": n, "batch_per_gpu": per_gpu, "global_batch": per_gpu * world,
+                       "parallelism": f"batch-shard x{world}", "launches_per_step": launches_per_step},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profile(kernel_name),
+                         "kernel": f"fft_stockham_kernel<float,{int(np.log2(n))},{kernel_name}...>",
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "launch_ms_avg": launch_ms, "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
+        }
+        if gather:
+            out["gather"] = gather
+        if world == 1 and not args.no_cpu_baseline:
+            rows = 2048
+            sel = torch.cat([torch.arange(0, rows // 2), torch.arange(per_gpu // 2, per_gpu // 2 + rows // 2)]) \
+                if args.workload != "spectrum16k" else torch.arange(0, min(rows, re.shape[0]))
+            hre = re[sel.to(dev)].cpu().numpy().astype(np.float64)
+            him = im[sel.to(dev)].cpu().numpy().astype(np.float64) if im is not None else None
+            out["cpu_baseline"] = cpu_baseline(hre, him, n, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,191 @@
+/*
+ * pdsp_hip.h -- C ABI of the MI355X (gfx950) batched FFT / spectrum engine that
+ * re-backs pragma-dsp's hot path.  Plain pointers and sizes only; no torch, no
+ * C++ types.  Built as pragma-dsp_amd/csrc/libpdsp_hip.so.
+ *
+ * Every entry point cites the reference interface (relative to the pragma-dsp
+ * repository) whose work it replaces.  The reference has no FFI today (it is
+ * pure TypeScript); the binding a maintainer would add (N-API addon) is in
+ * pragma-dsp_amd/csrc/pdsp_napi.c and is described in INTEGRATION.md.
+ *
+ * Conventions (src/core/fft.ts:89-151, PLAN.md:104-128):
+ *   forward  X[k] = sum_n x[n] e^{-j 2 pi k n / N}   (no normalisation)
+ *   inverse  x[n] = (1/N) sum_k X[k] e^{+j 2 pi k n / N}
+ *   complex data is PLANAR {real[], imag[]} like the reference's ComplexArray;
+ *   a batch is `batch` rows of N contiguous values: re[b*N + i], im[b*N + i].
+ *
+ * Two families:
+ *   *_f32 / *_f64 with `pdsp_stream`  -- DEVICE pointers, asynchronous on the
+ *       given HIP stream (0 = the null stream).  This is the throughput path
+ *       (bench, batched callers).
+ *   *_host_f64                        -- HOST f64 pointers, synchronous.  This
+ *       is what the JS drop-in (`Radix2Fft`, `FFT`, `spectrum`) binds: the
+ *       reference API is Float64Array in / Float64Array out.
+ *
+ * Return value: 0 (PDSP_OK) or a pdsp_status; pdsp_last_error() then returns a
+ * thread-local message.  For the argument errors the reference throws on, the
+ * message is the reference's exact text, and validation happens before any
+ * device work.
+ */
+#ifndef PDSP_HIP_H
+#define PDSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDSP_API __attribute__((visibility("default")))
+
+typedef struct pdsp_plan pdsp_plan; /* replaces a Radix2Fft instance, src/core/fft.ts:63-75 */
+typedef void *pdsp_stream;          /* a hipStream_t, passed as an opaque pointer */
+
+typedef enum pdsp_status {
+  PDSP_OK = 0,
+  PDSP_ERR_SIZE_NOT_POW2 = 1,   /* "FFT size must be power of two, got ${size}"  fft.ts:69-71, fourier.ts:74-76 */
+  PDSP_ERR_INPUT_LENGTH = 2,    /* "FFT input length ${len} != size ${N}"         fft.ts:95-104 */
+  PDSP_ERR_WINDOW_SIZE = 3,     /* "Window size must be positive, got ${size}"    fourier.ts:15-17 */
+  PDSP_ERR_WINDOW_LENGTH = 4,   /* "Window length must match input length."       fourier.ts:59-61 */
+  PDSP_ERR_WINDOW_TYPE = 5,     /* "Unsupported window type: ${t}"                fourier.ts:47-50 */
+  PDSP_ERR_FFT_SIZE = 6,        /* "FFT size must be positive, got ${size}"       fourier.ts:152-154 */
+  PDSP_ERR_SAMPLE_RATE = 7,     /* "Sample rate must be positive, got ${sr}"      fourier.ts:155-157 */
+  PDSP_ERR_UNSUPPORTED_SIZE = 8,/* power of two, but beyond what the single-pass LDS kernel holds */
+  PDSP_ERR_BAD_ARG = 9,         /* null pointer / negative batch */
+  PDSP_ERR_DEVICE = 10          /* no GPU, or a HIP runtime error (message has the HIP text) */
+} pdsp_status;
+
+typedef enum pdsp_window {      /* WindowType, src/xform/fourier.ts:11 */
+  PDSP_WIN_RECT = 0,
+  PDSP_WIN_HANN = 1,
+  PDSP_WIN_HAMMING = 2,
+  PDSP_WIN_BLACKMAN = 3
+} pdsp_window;
+
+typedef enum pdsp_sides {       /* FftSides, src/xform/fourier.ts:12 */
+  PDSP_SIDES_ONE = 0,
+  PDSP_SIDES_TWO = 1
+} pdsp_sides;
+
+typedef struct pdsp_peak {      /* SpectrumPeak, src/public/spectrum.ts:15-20 */
+  int32_t index;
+  double frequency;
+  double amplitude;
+  double phase;
+} pdsp_peak;
+
+/* ---- library ---------------------------------------------------------- */
+
+PDSP_API int pdsp_version(void);
+PDSP_API const char *pdsp_last_error(void);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+PDSP_API int pdsp_device_count(void);
+/* Largest N the single-pass kernels take for 4-byte / 8-byte scalars. */
+PDSP_API int pdsp_max_size(int scalar_bytes);
+
+/* ---- host-side index math (no device) --------------------------------- */
+
+/* isPowerOfTwo, src/core/fft.ts:16 (integers only). */
+PDSP_API int pdsp_is_pow2(long long n);
+/* nextPowerOfTwo, src/core/fft.ts:18-23 (no int32 overflow). */
+PDSP_API long long pdsp_next_pow2(long long n);
+/* createWindow, src/xform/fourier.ts:14-52.  Host, f64 (an f32 window misses
+ * the reference's 1e-8 window tolerance). */
+PDSP_API int pdsp_window_make(int type, long long size, double *out);
+/* binFrequencies, src/xform/fourier.ts:147-165.  `out` holds size/2+1 (one) or
+ * size (two) values; *bins_out receives the count. */
+PDSP_API int pdsp_bin_frequencies(long long size, double sample_rate, int sides,
+                                  double *out, long long *bins_out);
+/* fftShift, src/xform/fourier.ts:122-134: out[i] = in[(i + floor(n/2)) % n]. */
+PDSP_API int pdsp_fft_shift_f64(const double *in, long long n, double *out);
+/* findPeak, src/public/spectrum.ts:74-105 (strict '>', DC skipped unless no
+ * other bin is > 0).  Returns the index (>= 0). */
+PDSP_API long long pdsp_find_peak_f64(const double *amplitude, long long bins);
+
+/* ---- plan -------------------------------------------------------------- */
+
+/* new Radix2Fft(size) / new FFT(size): src/core/fft.ts:68-75,
+ * src/xform/fourier.ts:73-79.  Builds the twiddle tables on the host in f64 and
+ * uploads them to `device` (-1 = the current HIP device).  The bit-reversal
+ * table of fft.ts:25-38 has no counterpart: the Stockham kernel autosorts. */
+PDSP_API int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out);
+PDSP_API int pdsp_plan_destroy(pdsp_plan *plan);
+PDSP_API long long pdsp_plan_size(const pdsp_plan *plan);
+PDSP_API int pdsp_plan_device(const pdsp_plan *plan);
+
+/* ---- device-pointer batched transforms (f32) --------------------------- */
+
+/* Radix2Fft.forward(input) row by row, src/core/fft.ts:77-79: real input,
+ * imaginary part taken as zero.  re_in[batch*N] -> re_out, im_out[batch*N]. */
+PDSP_API int pdsp_fft_forward_real_f32(const pdsp_plan *plan, long long batch,
+                                       const float *re_in, float *re_out, float *im_out,
+                                       pdsp_stream stream);
+/* Radix2Fft.forwardComplex, src/core/fft.ts:81-83. */
+PDSP_API int pdsp_fft_forward_complex_f32(const pdsp_plan *plan, long long batch,
+                                          const float *re_in, const float *im_in,
+                                          float *re_out, float *im_out, pdsp_stream stream);
+/* Radix2Fft.inverse (conjugate twiddles + 1/N), src/core/fft.ts:85-87, :142-148. */
+PDSP_API int pdsp_fft_inverse_f32(const pdsp_plan *plan, long long batch,
+                                  const float *re_in, const float *im_in,
+                                  float *re_out, float *im_out, pdsp_stream stream);
+
+/* ---- device-pointer elementwise helpers (f32) -------------------------- */
+
+/* applyWindow row by row, src/xform/fourier.ts:54-67: out[b][i] = in[b][i]*win[i]. */
+PDSP_API int pdsp_apply_window_f32(long long batch, long long n, const float *in,
+                                   const float *window, float *out, pdsp_stream stream);
+/* magnitude, src/xform/fourier.ts:98-109 (sqrt(re^2+im^2) in f32; not the
+ * overflow-safe hypot: fine for |X| < 1e19). */
+PDSP_API int pdsp_magnitude_f32(long long count, const float *re, const float *im,
+                                float *out, pdsp_stream stream);
+/* phase, src/xform/fourier.ts:111-120: atan2(im, re). */
+PDSP_API int pdsp_phase_f32(long long count, const float *re, const float *im,
+                            float *out, pdsp_stream stream);
+
+/* ---- fused spectrum (f32) ---------------------------------------------- */
+
+/* The batched body of spectrum(), src/public/spectrum.ts:116-131, one frame per
+ * row, fused in one kernel: buildFrame (zero-pad / truncate to N, :36-43) ->
+ * applyWindow -> forward FFT -> magnitude -> one-/two-sided amplitude scaling
+ * (:45-72) [-> phase, :122,128-131] [-> findPeak index, :74-105].
+ *   frames      [batch][frame_stride] real samples; the first
+ *               min(frame_len, N) of each row are used, the rest is zero.
+ *   window      N device floats, or NULL for "rect".
+ *   amp_out     [batch][bins], bins = N/2+1 (one-sided) or N (two-sided).
+ *   phase_out   same shape, or NULL.
+ *   peak_out    [batch] int32 peak bin per frame, or NULL. */
+PDSP_API int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch,
+                               const float *frames, long long frame_len, long long frame_stride,
+                               const float *window, int sides,
+                               float *amp_out, float *phase_out, int32_t *peak_out,
+                               pdsp_stream stream);
+
+/* ---- host f64 drop-in entry points (synchronous) ----------------------- */
+
+/* Radix2Fft.transform, src/core/fft.ts:89-151, for `batch` rows.  im_in may be
+ * NULL (= forward(real)).  in_len is the caller's row length and must equal N
+ * (PDSP_ERR_INPUT_LENGTH otherwise, message as fft.ts:95-104).  Computes in f32
+ * on the device (f64 at the boundary, SURVEY section 8 conventions). */
+PDSP_API int pdsp_fft_transform_host_f64(pdsp_plan *plan, long long batch, long long in_len,
+                                         const double *re_in, const double *im_in,
+                                         double *re_out, double *im_out, int inverse);
+/* applyWindow / magnitude / phase on host arrays (fourier.ts:54-67, :98-120).
+ * Small inputs: done by launching the same device kernels. */
+PDSP_API int pdsp_apply_window_host_f64(const double *in, long long in_len, const double *window,
+                                        long long window_len, double *out);
+PDSP_API int pdsp_magnitude_host_f64(const double *re, const double *im, long long n, double *out);
+PDSP_API int pdsp_phase_host_f64(const double *re, const double *im, long long n, double *out);
+/* spectrum(samples, options), src/public/spectrum.ts:107-142.  fft_size < 0
+ * means "absent" = nextPowerOfTwo(len) (0 is rejected like `new FFT(0)`).  freq/amp/phase hold bins values (N/2+1 or N);
+ * *bins_out receives the count.  Peak search runs on the host over the
+ * f64-promoted amplitudes so the strict-'>' / first-wins rules are exact. */
+PDSP_API int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_rate,
+                                    long long fft_size, int window, int sides,
+                                    double *freq_out, double *amp_out, double *phase_out,
+                                    pdsp_peak *peak_out, long long *bins_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDSP_HIP_H */

@@ -1,0 +1,156 @@
+"""Device-resident batched API (an extension: the reference has no batch shape,
+only the caller loop of bench/reallife/signals.ts:264-270).  Row b of every call
+means exactly `Radix2Fft.forward / forwardComplex / inverse` or the body of
+`spectrum()` applied to row b.
+
+torch is used for device memory and streams only; the arithmetic is the HIP
+kernels behind include/pdsp_hip.h, reached with raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import PdspError, check, lib
+from .core import isPowerOfTwo, js_num
+from .fourier import createWindow
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class BatchedFft:
+    """One plan, many rows.  Tensors are float32, contiguous, shape [..., N], on the plan's GPU."""
+
+    def __init__(self, size, device=None):
+        if not isPowerOfTwo(size):
+            raise PdspError(_capi.ERR_SIZE_NOT_POW2, f"FFT size must be power of two, got {js_num(size)}")
+        if not torch.cuda.is_available():
+            raise PdspError(_capi.ERR_DEVICE, "no HIP device available (the pdsp engine has no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.size = int(size)
+        handle = C.c_void_p()
+        check(lib.pdsp_plan_create(self.size, self.device.index, C.byref(handle)))
+        self._h = handle
+        self._windows = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib.pdsp_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- helpers -------------------------------------------------------------
+    def _check(self, t, name, last=None):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise PdspError(_capi.ERR_BAD_ARG, f"{name} must be a contiguous float32 tensor on {self.device}")
+        if t.device != self.device:
+            raise PdspError(_capi.ERR_BAD_ARG, f"{name} is on {t.device}, plan is on {self.device}")
+        want = self.size if last is None else last
+        if t.shape[-1] != want:
+            raise PdspError(_capi.ERR_INPUT_LENGTH, f"FFT input length {t.shape[-1]} != size {want}")
+
+    def _out(self, like, out):
+        if out is not None:
+            ore, oim = out
+            self._check(ore, "out.real")
+            self._check(oim, "out.imag")
+            return ore, oim
+        return torch.empty_like(like), torch.empty_like(like)
+
+    def window(self, kind: str) -> torch.Tensor:
+        """Device copy (f32) of createWindow(kind, N); cached per kind like
+        FourierLive's window cache (src/effect/index.ts:39-48)."""
+        w = self._windows.get(kind)
+        if w is None:
+            w = torch.from_numpy(createWindow(kind, self.size).astype(np.float32)).to(self.device)
+            self._windows[kind] = w
+        return w
+
+    # -- transforms ------------------------------------------------------------
+    def forward(self, re: torch.Tensor, im: torch.Tensor | None = None, out=None):
+        """Rows of Radix2Fft.forward (im None) or .forwardComplex."""
+        self._check(re, "input.real")
+        batch = re.numel() // self.size if self.size else 0
+        ore, oim = self._out(re, out)
+        s = _stream_ptr(self.device)
+        if im is None:
+            check(lib.pdsp_fft_forward_real_f32(self._h, batch, _ptr(re), _ptr(ore), _ptr(oim), s))
+        else:
+            self._check(im, "input.imag")
+            check(lib.pdsp_fft_forward_complex_f32(self._h, batch, _ptr(re), _ptr(im), _ptr(ore), _ptr(oim), s))
+        return ore, oim
+
+    def inverse(self, re: torch.Tensor, im: torch.Tensor, out=None):
+        self._check(re, "input.real")
+        self._check(im, "input.imag")
+        batch = re.numel() // self.size
+        ore, oim = self._out(re, out)
+        check(lib.pdsp_fft_inverse_f32(self._h, batch, _ptr(re), _ptr(im), _ptr(ore), _ptr(oim),
+                                       _stream_ptr(self.device)))
+        return ore, oim
+
+    def spectrum(self, frames: torch.Tensor, window="rect", sides: str = "one", want_phase: bool = False,
+                 want_peak: bool = False, out=None):
+        """Rows of spectrum()'s body: frames [..., L] (L <= N zero-padded, L > N
+        truncated: spectrum.ts:36-43) -> amplitude [..., bins] (+ phase, + peak bin)."""
+        if frames.dtype != torch.float32 or not frames.is_cuda or not frames.is_contiguous():
+            raise PdspError(_capi.ERR_BAD_ARG, "frames must be a contiguous float32 CUDA tensor")
+        length = frames.shape[-1]
+        batch = frames.numel() // length if length else 0
+        two = sides != "one"
+        bins = self.size if two else self.size // 2 + 1
+        if isinstance(window, str):
+            if self.size != 1 and window not in _capi.WINDOW_TYPES:
+                raise PdspError(_capi.ERR_WINDOW_TYPE, f"Unsupported window type: {window}")
+            win = None if (window == "rect" or self.size == 1) else self.window(window)
+        else:
+            win = window
+            if win is not None:
+                if win.shape[-1] != self.size:
+                    raise PdspError(_capi.ERR_WINDOW_LENGTH, "Window length must match input length.")
+                self._check(win, "window")
+        shape = tuple(frames.shape[:-1])
+        amp = out if out is not None else torch.empty(shape + (bins,), dtype=torch.float32, device=self.device)
+        ph = torch.empty(shape + (bins,), dtype=torch.float32, device=self.device) if want_phase else None
+        pk = torch.empty(shape, dtype=torch.int32, device=self.device) if want_peak else None
+        check(lib.pdsp_spectrum_f32(self._h, batch, _ptr(frames), min(length, self.size), length, _ptr(win),
+                                    1 if two else 0, _ptr(amp), _ptr(ph), _ptr(pk), _stream_ptr(self.device)))
+        return amp, ph, pk
+
+
+# -- stand-alone element-wise device helpers ----------------------------------
+
+def apply_window(frames: torch.Tensor, window: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    if frames.shape[-1] != window.shape[-1]:
+        raise PdspError(_capi.ERR_WINDOW_LENGTH, "Window length must match input length.")
+    out = torch.empty_like(frames) if out is None else out
+    n = frames.shape[-1]
+    check(lib.pdsp_apply_window_f32(frames.numel() // n if n else 0, n, _ptr(frames), _ptr(window), _ptr(out),
+                                    _stream_ptr(frames.device)))
+    return out
+
+
+def magnitude(re: torch.Tensor, im: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    out = torch.empty_like(re) if out is None else out
+    check(lib.pdsp_magnitude_f32(re.numel(), _ptr(re), _ptr(im), _ptr(out), _stream_ptr(re.device)))
+    return out
+
+
+def phase(re: torch.Tensor, im: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    out = torch.empty_like(re) if out is None else out
+    check(lib.pdsp_phase_f32(re.numel(), _ptr(re), _ptr(im), _ptr(out), _stream_ptr(re.device)))
+    return out

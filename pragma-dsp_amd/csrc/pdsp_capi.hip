@@ -1,0 +1,574 @@
+// pdsp_capi.hip -- the C ABI of include/pdsp_hip.h: argument validation with the
+// reference's error texts, plan objects, kernel dispatch by size, and the
+// synchronous host-f64 entry points the JS drop-in binds.
+//
+// Product path only: nothing here touches oracle/, and there is no CPU fallback --
+// without a HIP device every compute entry point fails with PDSP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pdsp_hip.h"
+#include "pdsp_fft_kernel.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define PDSP_HIP_TRY(expr)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #expr); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && dev >= 0 && dev != prev) {
+      err = hipSetDevice(dev);
+      switched = (err == hipSuccess);
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+int ilog2ll(long long n) {
+  int l = 0;
+  while ((1LL << l) < n) ++l;
+  return l;
+}
+
+}  // namespace
+
+struct pdsp_plan {
+  long long n = 0;
+  int log2n = 0;
+  int device = -1;
+  float2 *d_tw32 = nullptr;
+  // host-f64 entry points: one stream + growing staging buffers per plan
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  float *h_stage = nullptr;  // pinned
+  size_t h_floats = 0;
+  float *d_stage = nullptr;
+  size_t d_floats = 0;
+  float *d_win[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+// Twiddle table for pdsp_radix.h's layout, built in f64 on the host
+// (src/core/fft.ts:45-61 builds cos/sin of (-2*pi*k)/m per stage with Math.cos /
+// Math.sin; same direct evaluation here, no recurrence), then rounded once.
+template <typename T2>
+std::vector<T2> build_twiddles(int log2n) {
+  const pdsp::RadixPlan p = pdsp::make_radix_plan(log2n);
+  std::vector<T2> tw((size_t)(p.twcount > 0 ? p.twcount : 1));
+  for (int i = 0; i < p.np; ++i) {
+    const int ns = p.ns[i], r = p.r[i];
+    if (ns <= 1) continue;
+    const double m = (double)ns * (double)r;
+    for (int rr = 1; rr < r; ++rr)
+      for (int k = 0; k < ns; ++k) {
+        const double angle = (-2.0 * M_PI * (double)rr * (double)k) / m;
+        T2 w;
+        w.x = (decltype(w.x))std::cos(angle);
+        w.y = (decltype(w.y))std::sin(angle);
+        tw[(size_t)p.twoff[i] + (size_t)(rr - 1) * ns + k] = w;
+      }
+  }
+  return tw;
+}
+
+template <int LOG2N, class LD, class ST>
+hipError_t launch_one(const LD &ld, const ST &st, const float2 *tw, long long batch, hipStream_t s) {
+  using TR = pdsp::FftTraits<LOG2N>;
+  const long long blocks = (batch + TR::ROWS - 1) / TR::ROWS;
+  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, LOG2N, LD, ST>), dim3((unsigned)blocks), dim3(TR::WG), 0,
+                     s, ld, st, tw, batch);
+  return hipGetLastError();
+}
+
+template <class LD, class ST>
+hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, long long batch, hipStream_t s) {
+  switch (log2n) {
+#define PDSP_CASE(L) \
+  case L:            \
+    return launch_one<L>(ld, st, tw, batch, s);
+    PDSP_CASE(0) PDSP_CASE(1) PDSP_CASE(2) PDSP_CASE(3) PDSP_CASE(4) PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7)
+    PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12) PDSP_CASE(13) PDSP_CASE(14)
+#undef PDSP_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+int check_plan_batch(const pdsp_plan *plan, long long batch) {
+  if (!plan) return fail(PDSP_ERR_BAD_ARG, "plan is null");
+  if (batch < 0) return fail(PDSP_ERR_BAD_ARG, "batch must be >= 0, got %lld", batch);
+  // grid.x limit; far beyond any HBM-resident batch
+  if (batch > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
+  return PDSP_OK;
+}
+
+int run_complex(const pdsp_plan *plan, long long batch, const float *re_in, const float *im_in, float *re_out,
+                float *im_out, float scale, hipStream_t s) {
+  if (batch == 0) return PDSP_OK;
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  hipError_t e;
+  pdsp::StoreComplex<float> st{re_out, im_out, plan->n, scale};
+  if (im_in) {
+    pdsp::LoadComplex<float> ld{re_in, im_in, plan->n};
+    e = launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, s);
+  } else {
+    pdsp::LoadReal<float> ld{re_in, plan->n};
+    e = launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, s);
+  }
+  PDSP_HIP_TRY(e);
+  return PDSP_OK;
+}
+
+int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 2048) b = 2048;  // grid-stride the rest (256 CUs x 8)
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int ensure_stage(pdsp_plan *plan, size_t floats) {
+  if (!plan->stream) PDSP_HIP_TRY(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking));
+  if (plan->h_floats < floats) {
+    if (plan->h_stage) (void)hipHostFree(plan->h_stage);
+    plan->h_stage = nullptr;
+    plan->h_floats = 0;
+    PDSP_HIP_TRY(hipHostMalloc((void **)&plan->h_stage, floats * sizeof(float), hipHostMallocDefault));
+    plan->h_floats = floats;
+  }
+  if (plan->d_floats < floats) {
+    if (plan->d_stage) (void)hipFree(plan->d_stage);
+    plan->d_stage = nullptr;
+    plan->d_floats = 0;
+    PDSP_HIP_TRY(hipMalloc((void **)&plan->d_stage, floats * sizeof(float)));
+    plan->d_floats = floats;
+  }
+  return PDSP_OK;
+}
+
+// Scratch (plan-less) staging for the element-wise host entry points.
+struct Scratch {
+  float *h = nullptr, *d = nullptr;
+  size_t n = 0;
+  ~Scratch() {
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+  }
+  int reserve(size_t floats) {
+    PDSP_HIP_TRY(hipHostMalloc((void **)&h, floats * sizeof(float), hipHostMallocDefault));
+    PDSP_HIP_TRY(hipMalloc((void **)&d, floats * sizeof(float)));
+    n = floats;
+    return PDSP_OK;
+  }
+};
+
+int require_device() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(PDSP_ERR_DEVICE, "no HIP device available (the pdsp engine has no CPU fallback)");
+  return PDSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdsp_version(void) { return 100; }
+
+const char *pdsp_last_error(void) { return g_err.c_str(); }
+
+int pdsp_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return count;
+}
+
+int pdsp_max_size(int scalar_bytes) {
+  if (scalar_bytes == 4) return 1 << pdsp::kMaxLog2N_f32;
+  return 0;
+}
+
+/* ---- host index math ---------------------------------------------------- */
+
+int pdsp_is_pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
+
+long long pdsp_next_pow2(long long n) {
+  if (n <= 1) return 1;
+  long long p = 1;
+  while (p < n && p < (1LL << 62)) p <<= 1;
+  return p;
+}
+
+int pdsp_window_make(int type, long long size, double *out) {
+  if (size <= 0) return fail(PDSP_ERR_WINDOW_SIZE, "Window size must be positive, got %lld", size);
+  if (!out) return fail(PDSP_ERR_BAD_ARG, "out is null");
+  if (size == 1) {  // fourier.ts:18-20 returns [1] before looking at the type
+    out[0] = 1.0;
+    return PDSP_OK;
+  }
+  if (type < PDSP_WIN_RECT || type > PDSP_WIN_BLACKMAN)
+    return fail(PDSP_ERR_WINDOW_TYPE, "Unsupported window type: %d", type);
+  const double denom = (double)(size - 1);
+  for (long long i = 0; i < size; ++i) {
+    const double f = (2.0 * M_PI * (double)i) / denom;
+    double v = 1.0;
+    if (type == PDSP_WIN_HANN) v = 0.5 * (1.0 - std::cos(f));
+    else if (type == PDSP_WIN_HAMMING) v = 0.54 - 0.46 * std::cos(f);
+    else if (type == PDSP_WIN_BLACKMAN) v = 0.42 - 0.5 * std::cos(f) + 0.08 * std::cos(2.0 * f);
+    out[i] = v;
+  }
+  return PDSP_OK;
+}
+
+int pdsp_bin_frequencies(long long size, double sample_rate, int sides, double *out, long long *bins_out) {
+  if (size <= 0) return fail(PDSP_ERR_FFT_SIZE, "FFT size must be positive, got %lld", size);
+  if (sample_rate <= 0) return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
+  const long long bins = sides == PDSP_SIDES_ONE ? size / 2 + 1 : size;
+  if (bins_out) *bins_out = bins;
+  if (out) {
+    const double scale = sample_rate / (double)size;
+    for (long long i = 0; i < bins; ++i) out[i] = (double)i * scale;
+  }
+  return PDSP_OK;
+}
+
+int pdsp_fft_shift_f64(const double *in, long long n, double *out) {
+  if (n < 0 || (n > 0 && (!in || !out))) return fail(PDSP_ERR_BAD_ARG, "bad fftShift arguments");
+  const long long mid = n / 2;
+  for (long long i = 0; i < n; ++i) out[i] = in[(i + mid) % n];
+  return PDSP_OK;
+}
+
+long long pdsp_find_peak_f64(const double *amp, long long bins) {
+  if (!amp || bins <= 0) return 0;
+  long long max_i = 0, nondc_i = 0;
+  double max_v = amp[0], nondc_v = 0.0;
+  bool has_nondc = false;
+  for (long long i = 1; i < bins; ++i) {
+    const double v = amp[i];
+    if (v > nondc_v) {
+      nondc_v = v;
+      nondc_i = i;
+    }
+    if (v > 0) has_nondc = true;
+    if (v > max_v) {
+      max_v = v;
+      max_i = i;
+    }
+  }
+  return has_nondc ? nondc_i : max_i;
+}
+
+/* ---- plan ----------------------------------------------------------------- */
+
+int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
+  if (!plan_out) return fail(PDSP_ERR_BAD_ARG, "plan_out is null");
+  *plan_out = nullptr;
+  if (!pdsp_is_pow2(size)) return fail(PDSP_ERR_SIZE_NOT_POW2, "FFT size must be power of two, got %lld", size);
+  const int log2n = ilog2ll(size);
+  if (log2n > pdsp::kMaxLog2N_f32)
+    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the single-pass limit %d", size,
+                1 << pdsp::kMaxLog2N_f32);
+  if (int rc = require_device()) return rc;
+  int count = 0;
+  PDSP_HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0) PDSP_HIP_TRY(hipGetDevice(&device));
+  if (device >= count) return fail(PDSP_ERR_BAD_ARG, "device %d out of range (%d visible)", device, count);
+  DeviceGuard g(device);
+  PDSP_HIP_TRY(g.err);
+  pdsp_plan *p = new (std::nothrow) pdsp_plan();
+  if (!p) return fail(PDSP_ERR_BAD_ARG, "out of host memory");
+  p->n = size;
+  p->log2n = log2n;
+  p->device = device;
+  const std::vector<float2> tw = build_twiddles<float2>(log2n);
+  hipError_t e = hipMalloc((void **)&p->d_tw32, tw.size() * sizeof(float2));
+  if (e == hipSuccess) e = hipMemcpy(p->d_tw32, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (p->d_tw32) (void)hipFree(p->d_tw32);
+    delete p;
+    return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) while uploading the twiddle table", (int)e, hipGetErrorString(e));
+  }
+  *plan_out = p;
+  return PDSP_OK;
+}
+
+int pdsp_plan_destroy(pdsp_plan *plan) {
+  if (!plan) return PDSP_OK;
+  {
+    DeviceGuard g(plan->device);
+    if (plan->stream) {
+      (void)hipStreamSynchronize(plan->stream);
+      (void)hipStreamDestroy(plan->stream);
+    }
+    if (plan->d_tw32) (void)hipFree(plan->d_tw32);
+    if (plan->d_stage) (void)hipFree(plan->d_stage);
+    if (plan->h_stage) (void)hipHostFree(plan->h_stage);
+    for (float *w : plan->d_win)
+      if (w) (void)hipFree(w);
+  }
+  delete plan;
+  return PDSP_OK;
+}
+
+long long pdsp_plan_size(const pdsp_plan *plan) { return plan ? plan->n : 0; }
+int pdsp_plan_device(const pdsp_plan *plan) { return plan ? plan->device : -1; }
+
+/* ---- device-pointer transforms --------------------------------------------- */
+
+int pdsp_fft_forward_real_f32(const pdsp_plan *plan, long long batch, const float *re_in, float *re_out,
+                              float *im_out, pdsp_stream stream) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (batch && (!re_in || !re_out || !im_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  return run_complex(plan, batch, re_in, nullptr, re_out, im_out, 1.0f, (hipStream_t)stream);
+}
+
+int pdsp_fft_forward_complex_f32(const pdsp_plan *plan, long long batch, const float *re_in, const float *im_in,
+                                 float *re_out, float *im_out, pdsp_stream stream) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (batch && (!re_in || !im_in || !re_out || !im_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  return run_complex(plan, batch, re_in, im_in, re_out, im_out, 1.0f, (hipStream_t)stream);
+}
+
+int pdsp_fft_inverse_f32(const pdsp_plan *plan, long long batch, const float *re_in, const float *im_in,
+                         float *re_out, float *im_out, pdsp_stream stream) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (batch && (!re_in || !im_in || !re_out || !im_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  // conj(FFT(conj(z))) == swap(FFT(swap(z))): the conjugated-twiddle sweep of
+  // fft.ts:122 is the forward kernel with the planes exchanged on the way in and
+  // out; the 1/N of fft.ts:142-148 rides on the store.
+  return run_complex(plan, batch, im_in, re_in, im_out, re_out, 1.0f / (float)plan->n, (hipStream_t)stream);
+}
+
+/* ---- device-pointer element-wise helpers ----------------------------------- */
+
+int pdsp_apply_window_f32(long long batch, long long n, const float *in, const float *window, float *out,
+                          pdsp_stream stream) {
+  if (batch < 0 || n < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
+  const long long total = batch * n;
+  if (total == 0) return PDSP_OK;
+  if (!in || !window || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  hipLaunchKernelGGL((pdsp::apply_window_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     in, window, out, total, n);
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
+int pdsp_magnitude_f32(long long count, const float *re, const float *im, float *out, pdsp_stream stream) {
+  if (count < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
+  if (count == 0) return PDSP_OK;
+  if (!re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  hipLaunchKernelGGL((pdsp::polar_kernel<float, false>), dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
+                     re, im, out, count);
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
+int pdsp_phase_f32(long long count, const float *re, const float *im, float *out, pdsp_stream stream) {
+  if (count < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
+  if (count == 0) return PDSP_OK;
+  if (!re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  hipLaunchKernelGGL((pdsp::polar_kernel<float, true>), dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
+                     re, im, out, count);
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
+/* ---- fused spectrum ---------------------------------------------------------- */
+
+int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
+                      long long frame_stride, const float *window, int sides, float *amp_out, float *phase_out,
+                      int32_t *peak_out, pdsp_stream stream) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
+  if (frame_len < 0 || frame_stride < frame_len) return fail(PDSP_ERR_BAD_ARG, "bad frame_len/frame_stride");
+  if (batch == 0) return PDSP_OK;
+  if (!frames || !amp_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  const long long n = plan->n;
+  const int bins = (int)(sides == PDSP_SIDES_ONE ? n / 2 + 1 : n);
+  pdsp::LoadFrameWindowed<float> ld{frames, window, frame_len < n ? frame_len : n, frame_stride};
+  pdsp::StoreAmplitude<float> st{amp_out, phase_out, bins,
+                                 // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
+                                 (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1,
+                                 1.0f / (float)n, (sides == PDSP_SIDES_ONE ? 2.0f : 1.0f) / (float)n};
+  PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, (hipStream_t)stream));
+  if (peak_out) {
+    hipLaunchKernelGGL((pdsp::find_peak_kernel<float>), dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       amp_out, bins, peak_out, batch);
+    PDSP_HIP_TRY(hipGetLastError());
+  }
+  return PDSP_OK;
+}
+
+/* ---- host f64 drop-in entry points ------------------------------------------ */
+
+int pdsp_fft_transform_host_f64(pdsp_plan *plan, long long batch, long long in_len, const double *re_in,
+                                const double *im_in, double *re_out, double *im_out, int inverse) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (in_len != plan->n) return fail(PDSP_ERR_INPUT_LENGTH, "FFT input length %lld != size %lld", in_len, plan->n);
+  if (batch == 0) return PDSP_OK;
+  if (!re_in || !re_out || !im_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  if (inverse && !im_in) return fail(PDSP_ERR_BAD_ARG, "inverse needs an imaginary plane");
+  std::lock_guard<std::mutex> lk(plan->mu);
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  const size_t cnt = (size_t)batch * (size_t)plan->n;
+  if (int rc = ensure_stage(plan, 4 * cnt)) return rc;
+  float *h_re = plan->h_stage, *h_im = h_re + cnt, *h_ore = h_im + cnt, *h_oim = h_ore + cnt;
+  float *d_re = plan->d_stage, *d_im = d_re + cnt, *d_ore = d_im + cnt, *d_oim = d_ore + cnt;
+  for (size_t i = 0; i < cnt; ++i) h_re[i] = (float)re_in[i];
+  if (im_in)
+    for (size_t i = 0; i < cnt; ++i) h_im[i] = (float)im_in[i];
+  hipStream_t s = plan->stream;
+  PDSP_HIP_TRY(hipMemcpyAsync(d_re, h_re, (im_in ? 2 : 1) * cnt * sizeof(float), hipMemcpyHostToDevice, s));
+  int rc;
+  if (inverse) rc = pdsp_fft_inverse_f32(plan, batch, d_re, d_im, d_ore, d_oim, s);
+  else if (im_in) rc = pdsp_fft_forward_complex_f32(plan, batch, d_re, d_im, d_ore, d_oim, s);
+  else rc = pdsp_fft_forward_real_f32(plan, batch, d_re, d_ore, d_oim, s);
+  if (rc) return rc;
+  PDSP_HIP_TRY(hipMemcpyAsync(h_ore, d_ore, 2 * cnt * sizeof(float), hipMemcpyDeviceToHost, s));
+  PDSP_HIP_TRY(hipStreamSynchronize(s));
+  for (size_t i = 0; i < cnt; ++i) re_out[i] = (double)h_ore[i];
+  for (size_t i = 0; i < cnt; ++i) im_out[i] = (double)h_oim[i];
+  return PDSP_OK;
+}
+
+int pdsp_apply_window_host_f64(const double *in, long long in_len, const double *window, long long window_len,
+                               double *out) {
+  if (in_len != window_len) return fail(PDSP_ERR_WINDOW_LENGTH, "Window length must match input length.");
+  if (in_len == 0) return PDSP_OK;
+  if (in_len < 0 || !in || !window || !out) return fail(PDSP_ERR_BAD_ARG, "bad applyWindow arguments");
+  if (int rc = require_device()) return rc;
+  Scratch sc;
+  const size_t n = (size_t)in_len;
+  if (int rc = sc.reserve(3 * n)) return rc;
+  for (size_t i = 0; i < n; ++i) sc.h[i] = (float)in[i];
+  for (size_t i = 0; i < n; ++i) sc.h[n + i] = (float)window[i];
+  PDSP_HIP_TRY(hipMemcpy(sc.d, sc.h, 2 * n * sizeof(float), hipMemcpyHostToDevice));
+  if (int rc = pdsp_apply_window_f32(1, in_len, sc.d, sc.d + n, sc.d + 2 * n, nullptr)) return rc;
+  PDSP_HIP_TRY(hipMemcpy(sc.h, sc.d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) out[i] = (double)sc.h[i];
+  return PDSP_OK;
+}
+
+static int polar_host(const double *re, const double *im, long long n_, double *out, bool want_phase) {
+  if (n_ == 0) return PDSP_OK;
+  if (n_ < 0 || !re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "bad magnitude/phase arguments");
+  if (int rc = require_device()) return rc;
+  Scratch sc;
+  const size_t n = (size_t)n_;
+  if (int rc = sc.reserve(3 * n)) return rc;
+  for (size_t i = 0; i < n; ++i) sc.h[i] = (float)re[i];
+  for (size_t i = 0; i < n; ++i) sc.h[n + i] = (float)im[i];
+  PDSP_HIP_TRY(hipMemcpy(sc.d, sc.h, 2 * n * sizeof(float), hipMemcpyHostToDevice));
+  const int rc = want_phase ? pdsp_phase_f32(n_, sc.d, sc.d + n, sc.d + 2 * n, nullptr)
+                            : pdsp_magnitude_f32(n_, sc.d, sc.d + n, sc.d + 2 * n, nullptr);
+  if (rc) return rc;
+  PDSP_HIP_TRY(hipMemcpy(sc.h, sc.d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) out[i] = (double)sc.h[i];
+  return PDSP_OK;
+}
+
+int pdsp_magnitude_host_f64(const double *re, const double *im, long long n, double *out) {
+  return polar_host(re, im, n, out, false);
+}
+
+int pdsp_phase_host_f64(const double *re, const double *im, long long n, double *out) {
+  return polar_host(re, im, n, out, true);
+}
+
+int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_rate, long long fft_size, int window,
+                           int sides, double *freq_out, double *amp_out, double *phase_out, pdsp_peak *peak_out,
+                           long long *bins_out) {
+  if (len < 0 || (len > 0 && !samples)) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+  if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
+  // Error order of spectrum.ts:113-132: FFT ctor (power of two) -> createWindow
+  // (type; N == 1 returns before the type switch) -> ... -> binFrequencies (rate).
+  const long long n = fft_size >= 0 ? fft_size : pdsp_next_pow2(len);  // < 0: options.fftSize absent
+  if (!pdsp_is_pow2(n)) return fail(PDSP_ERR_SIZE_NOT_POW2, "FFT size must be power of two, got %lld", n);
+  if (n != 1 && (window < PDSP_WIN_RECT || window > PDSP_WIN_BLACKMAN))
+    return fail(PDSP_ERR_WINDOW_TYPE, "Unsupported window type: %d", window);
+  if (sample_rate <= 0) return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
+  if (!freq_out || !amp_out || !phase_out) return fail(PDSP_ERR_BAD_ARG, "null output");
+  pdsp_plan *plan = nullptr;
+  if (int rc = pdsp_plan_create(n, -1, &plan)) return rc;
+  struct PlanDrop {
+    pdsp_plan *p;
+    ~PlanDrop() { pdsp_plan_destroy(p); }
+  } drop{plan};
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
+  const long long used = len < n ? len : n;
+  // staging: [frame n][window n][amp bins][phase bins]
+  if (int rc = ensure_stage(plan, (size_t)(2 * n + 2 * bins))) return rc;
+  float *h = plan->h_stage, *d = plan->d_stage;
+  for (long long i = 0; i < used; ++i) h[i] = (float)samples[i];
+  for (long long i = used; i < n; ++i) h[i] = 0.0f;
+  const bool has_win = (n != 1 && window != PDSP_WIN_RECT);
+  if (has_win) {
+    std::vector<double> w((size_t)n);
+    if (int rc = pdsp_window_make(window, n, w.data())) return rc;
+    for (long long i = 0; i < n; ++i) h[n + i] = (float)w[(size_t)i];
+  }
+  hipStream_t s = plan->stream;
+  PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)(has_win ? 2 * n : n) * sizeof(float), hipMemcpyHostToDevice, s));
+  if (int rc = pdsp_spectrum_f32(plan, 1, d, n, n, has_win ? d + n : nullptr, sides, d + 2 * n, d + 2 * n + bins,
+                                 nullptr, s))
+    return rc;
+  PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * n, d + 2 * n, (size_t)(2 * bins) * sizeof(float), hipMemcpyDeviceToHost, s));
+  PDSP_HIP_TRY(hipStreamSynchronize(s));
+  for (long long i = 0; i < bins; ++i) amp_out[i] = (double)h[2 * n + i];
+  for (long long i = 0; i < bins; ++i) phase_out[i] = (double)h[2 * n + bins + i];
+  if (int rc = pdsp_bin_frequencies(n, sample_rate, sides, freq_out, nullptr)) return rc;
+  if (bins_out) *bins_out = bins;
+  if (peak_out) {
+    // findPeak on the host over the f64-promoted amplitudes: exact strict-'>'
+    // and first-wins behaviour
+    const long long pk = pdsp_find_peak_f64(amp_out, bins);
+    peak_out->index = (int32_t)pk;
+    peak_out->frequency = freq_out[pk];
+    peak_out->amplitude = amp_out[pk];
+    peak_out->phase = phase_out[pk];
+  }
+  return PDSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+// pdsp_fft_kernel.h -- single-pass, LDS-resident Stockham autosort FFT for gfx950.
+//
+// What it replaces: the body of Radix2Fft.transform, src/core/fft.ts:89-151 of
+// pragma-dsp (bit-reversal scatter + log2 N radix-2 sweeps over memory + the
+// inverse 1/N sweep), applied to `batch` independent rows, with the caller's
+// pre/post element-wise steps (applyWindow, magnitude, phase, amplitude scaling:
+// src/xform/fourier.ts:54-120, src/public/spectrum.ts:45-72) folded into the
+// first load and the last store.  HBM is touched once each way; every butterfly
+// stage runs out of registers and LDS.
+//
+// Shape: a transform is owned by TP = N/E threads with E points each in VGPRs.
+// Pass p does radix-Rp butterflies in registers (log2 Rp radix-2 stages with
+// compile-time constant twiddles), multiplies by the inter-pass twiddles
+// W_{Ns*Rp}^{r*k} from a host-built f64->f32 table, and hands the points to the
+// next pass through LDS in autosort order.  Global loads and stores are always
+// `row*N + tid + TP*q` -- unit stride across the lanes of a wave -- so the
+// bit-reversed scatter of the reference never happens in memory.
+//
+// No MFMA: an FFT is not a dense contraction; the kernel is bound by HBM
+// (16 B/sample at 3.75 flop/B), not by VALU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "pdsp_radix.h"
+
+namespace pdsp {
+
+template <typename T> struct vec2;
+template <> struct vec2<float> { using type = float2; };
+template <> struct vec2<double> { using type = double2; };
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// Fully unrolled loop whose index is a compile-time constant (register arrays
+// must never be indexed at run time: they would go to scratch).
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+constexpr int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+constexpr int bitrev(int x, int bits) {
+  int y = 0;
+  for (int b = 0; b < bits; ++b) {
+    y = (y << 1) | (x & 1);
+    x >>= 1;
+  }
+  return y;
+}
+
+// (re + i*im) *= W16^M,  W16 = e^{-2*pi*i/16},  0 <= M < 8.
+template <typename T, int M>
+__device__ __forceinline__ void mul_w16(T &re, T &im) {
+  constexpr T C1 = T(0.92387953251128673848);  // cos(pi/8)
+  constexpr T C2 = T(0.70710678118654752440);  // cos(pi/4)
+  constexpr T C3 = T(0.38268343236508977173);  // sin(pi/8)
+  if constexpr (M == 0) {
+  } else if constexpr (M == 4) {  // -i
+    const T t = re;
+    re = im;
+    im = -t;
+  } else if constexpr (M == 2) {  // (1 - i)/sqrt2
+    const T a = re, b = im;
+    re = (a + b) * C2;
+    im = (b - a) * C2;
+  } else if constexpr (M == 6) {  // (-1 - i)/sqrt2
+    const T a = re, b = im;
+    re = (b - a) * C2;
+    im = -(a + b) * C2;
+  } else {
+    constexpr T c = M == 1 ? C1 : M == 3 ? C3 : M == 5 ? -C3 : -C1;
+    constexpr T s = M == 1 ? -C3 : M == 3 ? -C1 : M == 5 ? -C1 : -C3;
+    const T a = re, b = im;
+    re = a * c - b * s;
+    im = a * s + b * c;
+  }
+}
+
+// In-register radix-R DFT (R = 2, 4, 8, 16) as log2 R decimation-in-frequency
+// radix-2 stages.  Output k ends up in slot bitrev(k).
+template <typename T, int R>
+__device__ __forceinline__ void fft_reg(T (&ar)[R], T (&ai)[R]) {
+  static_assert(R >= 1 && R <= 16 && (R & (R - 1)) == 0, "radix");
+  static_for<ilog2(R)>([&](auto stc) {
+    constexpr int s = R >> (stc + 1);  // half length of this stage's sub-transforms
+    static_for<R / 2>([&](auto ic) {
+      constexpr int g = (ic / s) * 2 * s, k = ic % s;
+      constexpr int i0 = g + k, i1 = i0 + s;
+      const T ur = ar[i0], ui = ai[i0], vr = ar[i1], vi = ai[i1];
+      ar[i0] = ur + vr;
+      ai[i0] = ui + vi;
+      T dr = ur - vr, di = ui - vi;
+      mul_w16<T, k *(8 / s)>(dr, di);  // W_{2s}^k
+      ar[i1] = dr;
+      ai[i1] = di;
+    });
+  });
+}
+
+template <int LOG2N>
+struct FftTraits {
+  static constexpr RadixPlan P = make_radix_plan(LOG2N);
+  static constexpr int N = P.n, E = P.e, TP = P.tp, NP = P.np;
+  static constexpr int WG = TP >= 256 ? TP : 256;  // threads per workgroup
+  static constexpr int ROWS = WG / TP;             // transforms per workgroup
+  // one pad element every 16: the radix-16 scatter (stride 16 complex) would
+  // otherwise put a whole ds_write lane group on one bank
+  static constexpr int LROW = N + N / 16;
+  static constexpr int LDS_ELEMS = NP > 1 ? ROWS * LROW : 1;
+};
+
+__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
+
+// ---- load / store policies ------------------------------------------------
+// ld(row, i, re, im): fetch point i of row `row` (row is always < batch).
+// st(row, i, re, im): write point i.
+
+template <typename T>
+struct LoadComplex {  // forwardComplex / inverse (planes swapped by the caller)
+  const T *__restrict__ re;
+  const T *__restrict__ im;
+  long long n;
+  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)i;
+    a = re[o];
+    b = im[o];
+  }
+};
+
+template <typename T>
+struct LoadReal {  // Radix2Fft.forward: imaginary part is zero
+  const T *__restrict__ re;
+  long long n;
+  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
+    a = re[(size_t)row * (size_t)n + (size_t)i];
+    b = T(0);
+  }
+};
+
+template <typename T>
+struct LoadFrameWindowed {  // buildFrame + applyWindow, spectrum.ts:36-43, :116-119
+  const T *__restrict__ x;
+  const T *__restrict__ win;  // may be null: rect
+  long long frame_len;        // samples used per row (<= N); the rest reads as zero
+  long long stride;
+  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
+    T v = T(0);
+    if (i < frame_len) {
+      v = x[(size_t)row * (size_t)stride + (size_t)i];
+      if (win) v *= win[i];
+    }
+    a = v;
+    b = T(0);
+  }
+};
+
+template <typename T>
+struct StoreComplex {
+  T *__restrict__ re;
+  T *__restrict__ im;
+  long long n;
+  T scale;  // 1 forward, 1/N inverse (fft.ts:142-148); power of two => exact
+  __device__ __forceinline__ void operator()(long long row, int i, T a, T b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)i;
+    re[o] = a * scale;
+    im[o] = b * scale;
+  }
+};
+
+template <typename T>
+struct StoreAmplitude {  // magnitude + scaleAmplitude{One,Two}Sided [+ phase]
+  T *__restrict__ amp;
+  T *__restrict__ ph;  // may be null
+  int bins;            // N/2+1 or N
+  int nyq;             // N/2 for one-sided (that bin is not doubled), -1 for two-sided
+  T s_edge;            // 1/N
+  T s_mid;             // 2/N one-sided, 1/N two-sided
+  __device__ __forceinline__ void operator()(long long row, int i, T a, T b) const {
+    if (i < bins) {
+      const size_t o = (size_t)row * (size_t)bins + (size_t)i;
+      const T m = sqrt(a * a + b * b);
+      amp[o] = m * ((i == 0 || i == nyq) ? s_edge : s_mid);
+      if (ph) ph[o] = atan2(b, a);
+    }
+  }
+};
+
+// ---- the kernel -------------------------------------------------------------
+
+template <typename T, int LOG2N, class LD, class ST>
+__global__ void __launch_bounds__(FftTraits<LOG2N>::WG)
+fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__restrict__ tw,
+                    const long long batch) {
+  using TR = FftTraits<LOG2N>;
+  using T2 = typename vec2<T>::type;
+  constexpr int E = TR::E, TP = TR::TP, NP = TR::NP;
+
+  __shared__ T2 lds[TR::LDS_ELEMS];
+
+  const int tid = TP == 1 ? 0 : (int)(threadIdx.x % TP);
+  const int rloc = (int)(threadIdx.x / TP);
+  const long long row_raw = (long long)blockIdx.x * TR::ROWS + rloc;
+  const bool live = row_raw < batch;
+  // dead rows of the last workgroup recompute the last live row and skip the
+  // store, so that every thread reaches every barrier without predicated loads
+  const long long row = live ? row_raw : batch - 1;
+  T2 *const lrow = lds + (NP > 1 ? rloc * TR::LROW : 0);
+
+  T xr[E], xi[E];
+  static_for<E>([&](auto q) { ld(row, tid + TP * q, xr[q], xi[q]); });
+
+  static_for<NP>([&](auto pc) {
+    constexpr int p = pc;
+    constexpr int R = TR::P.r[p], Ns = TR::P.ns[p], EB = E / R, LR = ilog2(R);
+    constexpr bool last = (p == NP - 1);
+
+    static_for<EB>([&](auto bc) {
+      constexpr int b = bc;
+      T ar[R], ai[R];
+      static_for<R>([&](auto rc) {
+        ar[rc] = xr[b + rc * EB];
+        ai[rc] = xi[b + rc * EB];
+      });
+      const int j = tid + b * TP;  // butterfly index within the pass, 0 <= j < N/R
+      if constexpr (Ns > 1) {
+        const T2 *const twp = tw + TR::P.twoff[p] + (j & (Ns - 1));
+        static_for<R - 1>([&](auto rc) {
+          constexpr int r = rc + 1;
+          const T2 w = twp[(r - 1) * Ns];
+          const T a = ar[r], c = ai[r];
+          ar[r] = a * w.x - c * w.y;
+          ai[r] = a * w.y + c * w.x;
+        });
+      }
+      fft_reg<T, R>(ar, ai);
+      if constexpr (last) {
+        // Ns*R == N: output r of butterfly j is X[j + r*N/R] = slot b + r*EB
+        static_for<R>([&](auto rc) {
+          xr[b + rc * EB] = ar[bitrev(rc, LR)];
+          xi[b + rc * EB] = ai[bitrev(rc, LR)];
+        });
+      } else {
+        const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
+        static_for<R>([&](auto rc) {
+          T2 v;
+          v.x = ar[bitrev(rc, LR)];
+          v.y = ai[bitrev(rc, LR)];
+          lrow[lds_pad(j0 + rc * Ns)] = v;
+        });
+      }
+    });
+
+    if constexpr (!last) {
+      __syncthreads();
+      static_for<E>([&](auto q) {
+        const T2 v = lrow[lds_pad(tid + TP * q)];
+        xr[q] = v.x;
+        xi[q] = v.y;
+      });
+      if constexpr (p + 1 < NP - 1) __syncthreads();  // the next pass writes LDS again
+    }
+  });
+
+  if (live) {
+    static_for<E>([&](auto q) { st(row, tid + TP * q, xr[q], xi[q]); });
+  }
+}
+
+// ---- element-wise kernels (stand-alone applyWindow / magnitude / phase) -----
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+apply_window_kernel(const T *__restrict__ in, const T *__restrict__ win, T *__restrict__ out,
+                    long long total, long long n) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step)
+    out[i] = in[i] * win[i % n];
+}
+
+template <typename T, bool PHASE>
+__global__ void __launch_bounds__(256)
+polar_kernel(const T *__restrict__ re, const T *__restrict__ im, T *__restrict__ out, long long total) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const T a = re[i], b = im[i];
+    out[i] = PHASE ? atan2(b, a) : sqrt(a * a + b * b);
+  }
+}
+
+// findPeak per frame, spectrum.ts:74-105: among bins >= 1 the first bin holding
+// the largest value that is > 0; bin 0 when there is none (amplitudes are >= 0,
+// so the reference's global-max fallback can only land on bin 0).
+template <typename T>
+__global__ void __launch_bounds__(256)
+find_peak_kernel(const T *__restrict__ amp, int bins, int *__restrict__ peak, long long batch) {
+  __shared__ T sv[256];
+  __shared__ int si[256];
+  const long long row = blockIdx.x;
+  if (row >= batch) return;
+  const T *a = amp + (size_t)row * (size_t)bins;
+  T bv = T(0);
+  int bi = 0;
+  for (int i = 1 + (int)threadIdx.x; i < bins; i += 256) {
+    const T v = a[i];
+    if (v > bv) {  // strict: the earliest index wins inside a thread's stride
+      bv = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const T ov = sv[threadIdx.x + s];
+      const int oi = si[threadIdx.x + s];
+      const T mv = sv[threadIdx.x];
+      const int mi = si[threadIdx.x];
+      // larger value wins; equal values: smaller index (first-wins); index 0 = "none"
+      if (ov > mv || (ov == mv && oi != 0 && (mi == 0 || oi < mi))) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) peak[row] = si[0];
+}
+
+}  // namespace pdsp
