@@ -71,4 +71,8 @@ def test_spectrum_dropin(pdsp, oracle_mod):
             assert len(g.amplitude) == len(w["amplitude"])
             assert rel_err(g.amplitude, w["amplitude"]) <= TOL
             assert np.array_equal(g.frequencies, w["frequencies"])
-            assert g.peak.index == w["peak"]["index"]
+            # real input: bins k and N-k tie mathematically in two-sided mode and the
+            # strict '>' picks whichever rounding favours -- accept the mirror
+            n = len(g.frequencies) if sides == "two" else 0
+            assert g.peak.index in (w["peak"]["index"], (n - w["peak"]["index"]) % max(n, 1))
+            assert abs(g.peak.amplitude - w["peak"]["amplitude"]) <= TOL * w["amplitude"].max()
