@@ -206,7 +206,7 @@ ORACLE_API void oracle_fft_shift(const double *in, int n, double *out) {
  * -1 for size <= 0, -2 for sample_rate <= 0. */
 ORACLE_API int oracle_bin_frequencies(int size, double sample_rate, int two_sided, double *out) {
   if (size <= 0) return -1;
-  if (!(sample_rate > 0)) return -2;
+  if (sample_rate <= 0) return -2; /* `sampleRate <= 0` exactly (NaN passes, as in JS) */
   const int bins = two_sided ? size : size / 2 + 1;
   const double scale = sample_rate / (double)size;
   for (int i = 0; i < bins; ++i) out[i] = (double)i * scale;
