@@ -108,6 +108,7 @@ def main() -> int:
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--ramp-seconds", type=float, default=0.6, help="untimed clock-ramp before the warm-up steps")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of the output slabs")
     args = ap.parse_args()
 
@@ -176,6 +177,13 @@ def main() -> int:
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize(dev)
 
+    # Untimed clock ramp: a cold MI355X needs ~0.5 s of work before its clocks settle
+    # (first 20 launches measured 8 % slower than steady state); then the W warm-up steps.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     barrier()

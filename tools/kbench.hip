@@ -1,0 +1,186 @@
+// tools/kbench.hip -- standalone kernel micro-benchmark (development tool, not product).
+// Times the N=4096 x 65536 C2C kernel against copy kernels with the same and with
+// the ideal access pattern, interleaved in one process (guide rule 24).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I pragma-dsp_amd/csrc tools/kbench.hip -o tools/kbench
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "pdsp_fft_kernel.h"
+
+#define CK(x)                                                                       \
+  do {                                                                              \
+    hipError_t e = (x);                                                             \
+    if (e != hipSuccess) {                                                          \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+      exit(1);                                                                      \
+    }                                                                               \
+  } while (0)
+
+// copy with the FFT kernel's access pattern: one 256-thread WG per row, 16 dword
+// loads per plane per thread at tid + 256*q
+template <bool NT>
+__global__ void __launch_bounds__(256) copy_rowpattern(const float *__restrict__ re, const float *__restrict__ im,
+                                                       float *__restrict__ ore, float *__restrict__ oim) {
+  const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
+  float a[16], b[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    a[q] = NT ? __builtin_nontemporal_load(re + base + 256 * q) : re[base + 256 * q];
+    b[q] = NT ? __builtin_nontemporal_load(im + base + 256 * q) : im[base + 256 * q];
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if (NT) {
+      __builtin_nontemporal_store(a[q], ore + base + 256 * q);
+      __builtin_nontemporal_store(b[q], oim + base + 256 * q);
+    } else {
+      ore[base + 256 * q] = a[q];
+      oim[base + 256 * q] = b[q];
+    }
+  }
+}
+
+// classic float4 grid-stride copy of both planes
+__global__ void __launch_bounds__(256) copy_float4(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n4) {
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) out[i] = in[i];
+}
+
+template <typename T>
+struct LoadComplexNT {
+  const T *__restrict__ re;
+  const T *__restrict__ im;
+  long long n;
+  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)i;
+    a = __builtin_nontemporal_load(re + o);
+    b = __builtin_nontemporal_load(im + o);
+  }
+};
+template <typename T>
+struct StoreComplexNT {
+  T *__restrict__ re;
+  T *__restrict__ im;
+  long long n;
+  T scale;
+  __device__ __forceinline__ void operator()(long long row, int i, T a, T b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)i;
+    __builtin_nontemporal_store(a * scale, re + o);
+    __builtin_nontemporal_store(b * scale, im + o);
+  }
+};
+
+int main(int argc, char **argv) {
+  const int n = 4096;
+  const long long batch = argc > 1 ? atoll(argv[1]) : 65536;
+  const int rounds = argc > 2 ? atoi(argv[2]) : 10;
+  const size_t cnt = (size_t)batch * n;
+  float *re, *im, *ore, *oim;
+  CK(hipMalloc(&re, cnt * 4));
+  CK(hipMalloc(&im, cnt * 4));
+  CK(hipMalloc(&ore, cnt * 4));
+  CK(hipMalloc(&oim, cnt * 4));
+  {
+    std::vector<float> h(cnt);
+    unsigned s = 12345;
+    for (size_t i = 0; i < cnt; ++i) {
+      s = s * 1664525u + 1013904223u;
+      h[i] = ((s >> 8) & 0xffff) / 32768.0f - 1.0f;
+    }
+    CK(hipMemcpy(re, h.data(), cnt * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < cnt; ++i) {
+      s = s * 1664525u + 1013904223u;
+      h[i] = ((s >> 8) & 0xffff) / 32768.0f - 1.0f;
+    }
+    CK(hipMemcpy(im, h.data(), cnt * 4, hipMemcpyHostToDevice));
+  }
+  // twiddles
+  const pdsp::RadixPlan p = pdsp::make_radix_plan(12);
+  std::vector<float2> tw(p.twcount);
+  for (int i = 0; i < p.np; ++i) {
+    if (p.ns[i] <= 1) continue;
+    for (int r = 1; r < p.r[i]; ++r)
+      for (int k = 0; k < p.ns[i]; ++k) {
+        const double ang = -2.0 * M_PI * r * k / ((double)p.ns[i] * p.r[i]);
+        tw[p.twoff[i] + (r - 1) * p.ns[i] + k] = make_float2((float)cos(ang), (float)sin(ang));
+      }
+  }
+  float2 *dtw;
+  CK(hipMalloc(&dtw, tw.size() * sizeof(float2)));
+  CK(hipMemcpy(dtw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+
+  using TR = pdsp::FftTraits<12>;
+  struct Variant {
+    std::string name;
+    std::function<void()> run;
+    std::vector<float> ms;
+  };
+  std::vector<Variant> vs;
+  vs.push_back({"copy_float4", [&] {
+                  hipLaunchKernelGGL(copy_float4, dim3(2048), dim3(256), 0, 0, (const float4 *)re, (float4 *)ore, cnt / 4);
+                  hipLaunchKernelGGL(copy_float4, dim3(2048), dim3(256), 0, 0, (const float4 *)im, (float4 *)oim, cnt / 4);
+                }});
+  vs.push_back({"copy_rowpattern", [&] {
+                  hipLaunchKernelGGL(copy_rowpattern<false>, dim3(batch), dim3(256), 0, 0, re, im, ore, oim);
+                }});
+  vs.push_back({"copy_rowpattern_nt", [&] {
+                  hipLaunchKernelGGL(copy_rowpattern<true>, dim3(batch), dim3(256), 0, 0, re, im, ore, oim);
+                }});
+  vs.push_back({"fft_v1", [&] {
+                  pdsp::LoadComplex<float> ld{re, im, n};
+                  pdsp::StoreComplex<float> st{ore, oim, n, 1.0f};
+                  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
+                                     dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
+                }});
+  vs.push_back({"fft_v1_nt", [&] {
+                  LoadComplexNT<float> ld{re, im, n};
+                  StoreComplexNT<float> st{ore, oim, n, 1.0f};
+                  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
+                                     dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
+                }});
+  vs.push_back({"fft_v1_ntload", [&] {
+                  LoadComplexNT<float> ld{re, im, n};
+                  pdsp::StoreComplex<float> st{ore, oim, n, 1.0f};
+                  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
+                                     dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
+                }});
+  vs.push_back({"fft_v1_ntstore", [&] {
+                  pdsp::LoadComplex<float> ld{re, im, n};
+                  StoreComplexNT<float> st{ore, oim, n, 1.0f};
+                  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
+                                     dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
+                }});
+
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (auto &v : vs) v.run();  // warm-up
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r) {
+    for (auto &v : vs) {
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) v.run();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      v.ms.push_back(ms / 5);
+    }
+  }
+  CK(hipGetLastError());
+  const double bytes = 16.0 * cnt;
+  printf("%-22s %10s %10s %10s %10s\n", "variant", "med_ms", "min_ms", "med_GB/s", "max_GB/s");
+  for (auto &v : vs) {
+    std::sort(v.ms.begin(), v.ms.end());
+    const float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+    printf("%-22s %10.4f %10.4f %10.1f %10.1f\n", v.name.c_str(), med, mn, bytes / med / 1e6, bytes / mn / 1e6);
+  }
+  return 0;
+}
