@@ -1,0 +1,86 @@
+'use strict';
+// Drop-in for `pragma-dsp/core` (reference src/core/fft.ts): same exports, same
+// signatures, same error texts; the numeric work runs on the GPU through the addon.
+// Node-12 compatible (no `??`, no optional chaining).
+const native = require('./native');
+
+// fft.ts:6-14 -- `fill` goes to both planes
+function createComplexArray(size, fill) {
+  const real = new Float64Array(size);
+  const imag = new Float64Array(size);
+  if (fill !== undefined && fill !== 0) {
+    real.fill(fill);
+    imag.fill(fill);
+  }
+  return { real: real, imag: imag };
+}
+
+// fft.ts:16 -- plus an integer check (the reference's int32 coercion lets 2.5 through)
+function isPowerOfTwo(n) {
+  return typeof n === 'number' && Number.isInteger(n) && n > 0 && n <= 0x40000000 && (n & (n - 1)) === 0;
+}
+
+// fft.ts:18-23 (without the int32 overflow above 2^30)
+function nextPowerOfTwo(n) {
+  if (!(n > 1)) return 1;
+  return native.nextPow2(Math.ceil(n));
+}
+
+// ArrayLike<number> -> Float64Array; holes / undefined / null read as 0 (`input[i] ?? 0`)
+function toF64(input) {
+  if (input instanceof Float64Array) return input;
+  if (ArrayBuffer.isView(input)) return Float64Array.from(input);
+  const n = input.length >>> 0;
+  const out = new Float64Array(n);
+  for (let i = 0; i < n; i += 1) {
+    const v = input[i];
+    out[i] = v === undefined || v === null ? 0 : v;
+  }
+  return out;
+}
+
+class Radix2Fft {
+  constructor(size) {
+    if (!isPowerOfTwo(size)) {
+      throw new Error('FFT size must be power of two, got ' + size);
+    }
+    this._plan = native.planCreate(size); // freed by the addon's finalizer
+    Object.defineProperty(this, 'size', { value: size, enumerable: true, writable: false });
+  }
+
+  forward(input, out) {
+    return this._transform(input, null, out, false);
+  }
+
+  forwardComplex(input, out) {
+    return this._transform(input.real, input.imag, out, false);
+  }
+
+  inverse(input, out) {
+    return this._transform(input.real, input.imag, out, true);
+  }
+
+  _transform(inputReal, inputImag, out, inverse) {
+    if (inputReal.length !== this.size) {
+      throw new Error('FFT input length ' + inputReal.length + ' != size ' + this.size);
+    }
+    if (inputImag && inputImag.length !== this.size) {
+      throw new Error('FFT input length ' + inputImag.length + ' != size ' + this.size);
+    }
+    const result = out === undefined || out === null ? createComplexArray(this.size) : out;
+    const direct = result.real instanceof Float64Array && result.imag instanceof Float64Array &&
+      result.real.length === this.size && result.imag.length === this.size;
+    const ore = direct ? result.real : new Float64Array(this.size);
+    const oim = direct ? result.imag : new Float64Array(this.size);
+    native.transform(this._plan, toF64(inputReal), inputImag ? toF64(inputImag) : null, ore, oim, inverse);
+    if (!direct) {
+      for (let i = 0; i < this.size; i += 1) {
+        result.real[i] = ore[i];
+        result.imag[i] = oim[i];
+      }
+    }
+    return result; // the same object when `out` was supplied
+  }
+}
+
+module.exports = { createComplexArray, isPowerOfTwo, nextPowerOfTwo, Radix2Fft, _toF64: toF64 };
