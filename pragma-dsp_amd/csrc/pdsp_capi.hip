@@ -68,6 +68,10 @@ struct pdsp_plan {
   int log2n = 0;
   int device = -1;
   float2 *d_tw32 = nullptr;
+  // packed-real spectrum path (N >= 64): radix table of the N/2-point transform and
+  // the split twiddles W_N^k, 0 <= k <= N/4
+  float2 *d_tw32_half = nullptr;
+  float2 *d_twr32 = nullptr;
   // host-f64 entry points: one stream + growing staging buffers per plan
   std::mutex mu;
   hipStream_t stream = nullptr;
@@ -120,6 +124,37 @@ hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, l
     return launch_one<L>(ld, st, tw, batch, s);
     PDSP_CASE(0) PDSP_CASE(1) PDSP_CASE(2) PDSP_CASE(3) PDSP_CASE(4) PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7)
     PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12) PDSP_CASE(13) PDSP_CASE(14)
+#undef PDSP_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+template <int LOG2M>
+hipError_t launch_packed_one(bool vec2, const float *frames, const float *win, long long frame_len, long long stride,
+                             const float2 *tw, const float2 *twr, float *amp, float *ph, int two_sided, float s_edge,
+                             float s_mid, long long batch, hipStream_t s) {
+  using TR = pdsp::FftTraits<LOG2M>;
+  const dim3 grid((unsigned)((batch + TR::ROWS - 1) / TR::ROWS)), block(TR::WG);
+#define PDSP_LAUNCH(V, W)                                                                                      \
+  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, LOG2M, V, W>), grid, block, 0, s, frames, win, frame_len, \
+                     stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, batch)
+  if (vec2 && win) PDSP_LAUNCH(true, true);
+  else if (vec2) PDSP_LAUNCH(true, false);
+  else if (win) PDSP_LAUNCH(false, true);
+  else PDSP_LAUNCH(false, false);
+#undef PDSP_LAUNCH
+  return hipGetLastError();
+}
+
+template <class... A>
+hipError_t launch_packed(int log2m, A... a) {
+  switch (log2m) {
+#define PDSP_CASE(L) \
+  case L:            \
+    return launch_packed_one<L>(a...);
+    PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7) PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12)
+    PDSP_CASE(13)
 #undef PDSP_CASE
     default:
       return hipErrorInvalidValue;
@@ -319,8 +354,22 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
   const std::vector<float2> tw = build_twiddles<float2>(log2n);
   hipError_t e = hipMalloc((void **)&p->d_tw32, tw.size() * sizeof(float2));
   if (e == hipSuccess) e = hipMemcpy(p->d_tw32, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+  if (e == hipSuccess && log2n >= 6) {
+    const std::vector<float2> twh = build_twiddles<float2>(log2n - 1);
+    std::vector<float2> twr((size_t)(size / 4 + 1));
+    for (long long k = 0; k <= size / 4; ++k) {
+      const double angle = (-2.0 * M_PI * (double)k) / (double)size;
+      twr[(size_t)k] = make_float2((float)std::cos(angle), (float)std::sin(angle));
+    }
+    e = hipMalloc((void **)&p->d_tw32_half, twh.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(p->d_tw32_half, twh.data(), twh.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_twr32, twr.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(p->d_twr32, twr.data(), twr.size() * sizeof(float2), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     if (p->d_tw32) (void)hipFree(p->d_tw32);
+    if (p->d_tw32_half) (void)hipFree(p->d_tw32_half);
+    if (p->d_twr32) (void)hipFree(p->d_twr32);
     delete p;
     return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) while uploading the twiddle table", (int)e, hipGetErrorString(e));
   }
@@ -337,6 +386,8 @@ int pdsp_plan_destroy(pdsp_plan *plan) {
       (void)hipStreamDestroy(plan->stream);
     }
     if (plan->d_tw32) (void)hipFree(plan->d_tw32);
+    if (plan->d_tw32_half) (void)hipFree(plan->d_tw32_half);
+    if (plan->d_twr32) (void)hipFree(plan->d_twr32);
     if (plan->d_stage) (void)hipFree(plan->d_stage);
     if (plan->h_stage) (void)hipHostFree(plan->h_stage);
     for (float *w : plan->d_win)
@@ -423,12 +474,32 @@ int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch, const float *frame
   PDSP_HIP_TRY(g.err);
   const long long n = plan->n;
   const int bins = (int)(sides == PDSP_SIDES_ONE ? n / 2 + 1 : n);
-  pdsp::LoadFrameWindowed<float> ld{frames, window, frame_len < n ? frame_len : n, frame_stride};
-  pdsp::StoreAmplitude<float> st{amp_out, phase_out, bins,
-                                 // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
-                                 (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1,
-                                 1.0f / (float)n, (sides == PDSP_SIDES_ONE ? 2.0f : 1.0f) / (float)n};
-  PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, (hipStream_t)stream));
+  const long long used = frame_len < n ? frame_len : n;
+  if (used == 0) {  // an empty frame is all zeros: amplitude 0, atan2(0, 0) = 0, peak 0
+    PDSP_HIP_TRY(hipMemsetAsync(amp_out, 0, (size_t)batch * bins * sizeof(float), (hipStream_t)stream));
+    if (phase_out) PDSP_HIP_TRY(hipMemsetAsync(phase_out, 0, (size_t)batch * bins * sizeof(float), (hipStream_t)stream));
+    if (peak_out) PDSP_HIP_TRY(hipMemsetAsync(peak_out, 0, (size_t)batch * sizeof(int32_t), (hipStream_t)stream));
+    return PDSP_OK;
+  }
+  const float s_edge = 1.0f / (float)n, s_mid = (sides == PDSP_SIDES_ONE ? 2.0f : 1.0f) / (float)n;
+  if (plan->d_tw32_half && (window == nullptr || ((uintptr_t)window & 7) == 0)) {
+    // packed-real path: N/2-point complex transform + Hermitian split fused with the store
+    const bool vec2 = ((uintptr_t)frames & 7) == 0 && (frame_stride & 1) == 0 && (used & 1) == 0;
+    PDSP_HIP_TRY(launch_packed(plan->log2n - 1, vec2, frames, window, used, frame_stride, plan->d_tw32_half,
+                               plan->d_twr32, amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid, batch,
+                               (hipStream_t)stream));
+  } else {
+    pdsp::StoreAmplitude<float> st{amp_out, phase_out, bins,
+                                   // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
+                                   (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1, s_edge, s_mid};
+    if (window) {
+      pdsp::LoadFrameWindowed<float, true> ld{frames, window, used, frame_stride};
+      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, (hipStream_t)stream));
+    } else {
+      pdsp::LoadFrameWindowed<float, false> ld{frames, window, used, frame_stride};
+      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, (hipStream_t)stream));
+    }
+  }
   if (peak_out) {
     hipLaunchKernelGGL((pdsp::find_peak_kernel<float>), dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream,
                        amp_out, bins, peak_out, batch);

@@ -29,6 +29,14 @@
 
 namespace pdsp {
 
+// Development-only ablation switches (tools/kbench): 0 in every product build.
+//   1 = inter-pass twiddles from a constant instead of the table
+//   2 = no window load      4 = no Hermitian split (store |Z| of the half-size transform)
+#ifndef PDSP_EXPERIMENT
+#define PDSP_EXPERIMENT 0
+#endif
+constexpr int kExp = PDSP_EXPERIMENT;
+
 template <typename T> struct vec2;
 template <> struct vec2<float> { using type = float2; };
 template <> struct vec2<double> { using type = double2; };
@@ -147,18 +155,19 @@ struct LoadReal {  // Radix2Fft.forward: imaginary part is zero
   }
 };
 
-template <typename T>
+// Loads are unconditional (clamped address + select): a per-element `if` around a
+// load makes hipcc branch and drain vmcnt per element (cdna guide, section 5 item 4c).
+template <typename T, bool HAS_WIN>
 struct LoadFrameWindowed {  // buildFrame + applyWindow, spectrum.ts:36-43, :116-119
   const T *__restrict__ x;
-  const T *__restrict__ win;  // may be null: rect
-  long long frame_len;        // samples used per row (<= N); the rest reads as zero
+  const T *__restrict__ win;  // N values when HAS_WIN (rect otherwise)
+  long long frame_len;        // 1 <= samples used per row <= N; the rest reads as zero
   long long stride;
   __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
-    T v = T(0);
-    if (i < frame_len) {
-      v = x[(size_t)row * (size_t)stride + (size_t)i];
-      if (win) v *= win[i];
-    }
+    const int last = (int)frame_len - 1;
+    T v = x[(size_t)row * (size_t)stride + (size_t)(i < last ? i : last)];
+    v = i <= last ? v : T(0);
+    if constexpr (HAS_WIN) v *= win[i];
     a = v;
     b = T(0);
   }
@@ -195,7 +204,84 @@ struct StoreAmplitude {  // magnitude + scaleAmplitude{One,Two}Sided [+ phase]
   }
 };
 
-// ---- the kernel -------------------------------------------------------------
+// ---- the passes --------------------------------------------------------------
+
+// Runs every pass of the length-2^LOG2N transform on the E points each of the TP
+// cooperating threads holds.  LAST_TO_LDS = false: the result comes back in the
+// registers, X[tid + TP*q] in slot q.  LAST_TO_LDS = true: the last pass also
+// scatters to LDS, in natural order (X[k] at lds_pad(k)), for a consumer that needs
+// other threads' bins; the caller must __syncthreads() before reading it.
+template <typename T, int LOG2N, bool LAST_TO_LDS>
+__device__ __forceinline__ void fft_passes(T (&xr)[FftTraits<LOG2N>::E], T (&xi)[FftTraits<LOG2N>::E],
+                                           typename vec2<T>::type *const lrow,
+                                           const typename vec2<T>::type *__restrict__ tw, const int tid) {
+  using TR = FftTraits<LOG2N>;
+  using T2 = typename vec2<T>::type;
+  constexpr int E = TR::E, TP = TR::TP, NP = TR::NP;
+
+  static_for<NP>([&](auto pc) {
+    constexpr int p = pc;
+    constexpr int R = TR::P.r[p], Ns = TR::P.ns[p], EB = E / R, LR = ilog2(R);
+    constexpr bool last = (p == NP - 1);
+    constexpr bool to_lds = !last || LAST_TO_LDS;
+
+    static_for<EB>([&](auto bc) {
+      constexpr int b = bc;
+      T ar[R], ai[R];
+      static_for<R>([&](auto rc) {
+        ar[rc] = xr[b + rc * EB];
+        ai[rc] = xi[b + rc * EB];
+      });
+      const int j = tid + b * TP;  // butterfly index within the pass, 0 <= j < N/R
+      if constexpr (Ns > 1) {
+        const T2 *const twp = tw + TR::P.twoff[p] + (j & (Ns - 1));
+        static_for<R - 1>([&](auto rc) {
+          constexpr int r = rc + 1;
+          T2 w;
+          if constexpr (kExp & 1) {
+            w.x = T(0.999) + T(r) * T(1e-4);
+            w.y = T(0.03);
+          } else {
+            w = twp[(r - 1) * Ns];
+          }
+          const T a = ar[r], c = ai[r];
+          ar[r] = a * w.x - c * w.y;
+          ai[r] = a * w.y + c * w.x;
+        });
+      }
+      fft_reg<T, R>(ar, ai);
+      if constexpr (!to_lds) {
+        // Ns*R == N: output r of butterfly j is X[j + r*N/R] = slot b + r*EB
+        static_for<R>([&](auto rc) {
+          xr[b + rc * EB] = ar[bitrev(rc, LR)];
+          xi[b + rc * EB] = ai[bitrev(rc, LR)];
+        });
+      } else {
+        // autosort scatter; for the last pass (Ns*R == N) this is the natural order
+        const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
+        static_for<R>([&](auto rc) {
+          T2 v;
+          v.x = ar[bitrev(rc, LR)];
+          v.y = ai[bitrev(rc, LR)];
+          lrow[lds_pad(j0 + rc * Ns)] = v;
+        });
+      }
+    });
+
+    if constexpr (!last) {
+      __syncthreads();
+      static_for<E>([&](auto q) {
+        const T2 v = lrow[lds_pad(tid + TP * q)];
+        xr[q] = v.x;
+        xi[q] = v.y;
+      });
+      // the next pass writes LDS again (every pass but a register-resident last one)
+      if constexpr (p + 1 < NP - 1 || LAST_TO_LDS) __syncthreads();
+    }
+  });
+}
+
+// ---- the kernels ---------------------------------------------------------------
 
 template <typename T, int LOG2N, class LD, class ST>
 __global__ void __launch_bounds__(FftTraits<LOG2N>::WG)
@@ -218,62 +304,125 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
 
   T xr[E], xi[E];
   static_for<E>([&](auto q) { ld(row, tid + TP * q, xr[q], xi[q]); });
-
-  static_for<NP>([&](auto pc) {
-    constexpr int p = pc;
-    constexpr int R = TR::P.r[p], Ns = TR::P.ns[p], EB = E / R, LR = ilog2(R);
-    constexpr bool last = (p == NP - 1);
-
-    static_for<EB>([&](auto bc) {
-      constexpr int b = bc;
-      T ar[R], ai[R];
-      static_for<R>([&](auto rc) {
-        ar[rc] = xr[b + rc * EB];
-        ai[rc] = xi[b + rc * EB];
-      });
-      const int j = tid + b * TP;  // butterfly index within the pass, 0 <= j < N/R
-      if constexpr (Ns > 1) {
-        const T2 *const twp = tw + TR::P.twoff[p] + (j & (Ns - 1));
-        static_for<R - 1>([&](auto rc) {
-          constexpr int r = rc + 1;
-          const T2 w = twp[(r - 1) * Ns];
-          const T a = ar[r], c = ai[r];
-          ar[r] = a * w.x - c * w.y;
-          ai[r] = a * w.y + c * w.x;
-        });
-      }
-      fft_reg<T, R>(ar, ai);
-      if constexpr (last) {
-        // Ns*R == N: output r of butterfly j is X[j + r*N/R] = slot b + r*EB
-        static_for<R>([&](auto rc) {
-          xr[b + rc * EB] = ar[bitrev(rc, LR)];
-          xi[b + rc * EB] = ai[bitrev(rc, LR)];
-        });
-      } else {
-        const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
-        static_for<R>([&](auto rc) {
-          T2 v;
-          v.x = ar[bitrev(rc, LR)];
-          v.y = ai[bitrev(rc, LR)];
-          lrow[lds_pad(j0 + rc * Ns)] = v;
-        });
-      }
-    });
-
-    if constexpr (!last) {
-      __syncthreads();
-      static_for<E>([&](auto q) {
-        const T2 v = lrow[lds_pad(tid + TP * q)];
-        xr[q] = v.x;
-        xi[q] = v.y;
-      });
-      if constexpr (p + 1 < NP - 1) __syncthreads();  // the next pass writes LDS again
-    }
-  });
-
+  fft_passes<T, LOG2N, false>(xr, xi, lrow, tw, tid);
   if (live) {
     static_for<E>([&](auto q) { st(row, tid + TP * q, xr[q], xi[q]); });
   }
+}
+
+// Fused body of spectrum() for real frames, one frame per row, via the packed-real
+// identity: z[m] = x[2m] + i*x[2m+1] (a plain float2 view of the windowed frame),
+// Z = FFT_M(z) with M = N/2, then for each pair (k, M-k)
+//     E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / (2i),  t = W_N^k * O,
+//     X[k] = E + t,   X[M-k] = conj(E - t),          (k = 0 also yields X[M] = Nyquist)
+// and only |X| (scaled as scaleAmplitude{One,Two}Sided, spectrum.ts:45-72) and
+// optionally atan2 leave the chip.  Half the butterflies, half the LDS and half the
+// loads per thread of running the complex kernel on (x, 0).
+//   LOG2M = log2(N/2) >= 5.   twr[k] = e^{-2*pi*i*k/N}, 0 <= k <= M/2.
+template <typename T, int LOG2M, bool VEC2, bool HAS_WIN>
+__global__ void __launch_bounds__(FftTraits<LOG2M>::WG)
+spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, const long long frame_len,
+                       const long long stride, const typename vec2<T>::type *__restrict__ tw,
+                       const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp,
+                       T *__restrict__ ph, const int two_sided, const T s_edge, const T s_mid,
+                       const long long batch) {
+  using TR = FftTraits<LOG2M>;
+  using T2 = typename vec2<T>::type;
+  constexpr int E = TR::E, TP = TR::TP, M = TR::N;
+  static_assert(LOG2M >= 5, "packed path needs TP >= 2");
+
+  __shared__ T2 lds[TR::LDS_ELEMS];
+
+  const int tid = (int)(threadIdx.x % TP);
+  const int rloc = (int)(threadIdx.x / TP);
+  const long long row_raw = (long long)blockIdx.x * TR::ROWS + rloc;
+  const bool live = row_raw < batch;
+  const long long row = live ? row_raw : batch - 1;
+  T2 *const lrow = lds + rloc * TR::LROW;
+
+  // buildFrame + applyWindow (spectrum.ts:36-43, :116-119) on load.  Unconditional
+  // clamped loads + selects (no per-element branches); the host guarantees
+  // 1 <= frame_len <= N, and an even frame_len and 8-byte aligned rows when VEC2.
+  const T *const x = frames + (size_t)row * (size_t)stride;
+  const int flen = (int)frame_len;
+  T xr[E], xi[E];
+  static_for<E>([&](auto q) {
+    const int i0 = 2 * (tid + TP * q);
+    T a, b;
+    if constexpr (VEC2) {
+      const int c = i0 < flen - 2 ? i0 : flen - 2;
+      const T2 v = *reinterpret_cast<const T2 *>(x + c);
+      a = i0 < flen ? v.x : T(0);
+      b = i0 < flen ? v.y : T(0);
+    } else {
+      const int c0 = i0 < flen - 1 ? i0 : flen - 1, c1 = i0 + 1 < flen - 1 ? i0 + 1 : flen - 1;
+      const T v0 = x[c0], v1 = x[c1];
+      a = i0 < flen ? v0 : T(0);
+      b = i0 + 1 < flen ? v1 : T(0);
+    }
+    if constexpr (HAS_WIN && !(kExp & 2)) {
+      const T2 w = *reinterpret_cast<const T2 *>(win + i0);
+      a *= w.x;
+      b *= w.y;
+    }
+    xr[q] = a;
+    xi[q] = b;
+  });
+
+  fft_passes<T, LOG2M, true>(xr, xi, lrow, tw, tid);
+  __syncthreads();
+
+  if (!live) return;
+  const int bins = two_sided ? 2 * M : M + 1;
+  T *const arow = amp + (size_t)row * (size_t)bins;
+  T *const prow = ph ? ph + (size_t)row * (size_t)bins : nullptr;
+  // pairs k = tid + TP*q, q < E/2 (k < M/2); k = M/2 is one more pair for tid == 0
+  if constexpr (kExp & 4) {
+    static_for<E / 2 + 1>([&](auto qc) {
+      constexpr int q = qc;
+      if (q < E / 2 || tid == 0) {
+        const int k = tid + TP * q;
+        const T2 z = lrow[lds_pad(k)], zp = lrow[lds_pad((M - k) & (M - 1))];
+        arow[k] = sqrt(z.x * z.x + z.y * z.y);
+        arow[M - k] = sqrt(zp.x * zp.x + zp.y * zp.y);
+      }
+    });
+    return;
+  }
+  static_for<E / 2 + 1>([&](auto qc) {
+    constexpr int q = qc;
+    if (q < E / 2 || tid == 0) {
+      const int k = tid + TP * q;
+      const int kp = (M - k) & (M - 1);  // Z[M] == Z[0]
+      const T2 z = lrow[lds_pad(k)], zp = lrow[lds_pad(kp)];
+      const T2 w = twr[k];
+      const T er = T(0.5) * (z.x + zp.x), ei = T(0.5) * (z.y - zp.y);  // E
+      const T orr = T(0.5) * (z.y + zp.y), oi = T(0.5) * (zp.x - z.x);  // O = (Z - conj Zp)/(2i)
+      const T tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;     // t = W_N^k O
+      const T ar = er + tr, ai = ei + ti;                                // X[k]
+      const T br = er - tr, bi = -(ei - ti);                             // X[M-k]
+      const int k2 = M - k;
+      // bins 0 (DC, from k = 0) and M (Nyquist, the partner of k = 0) are not doubled
+      const T sc = (k == 0) ? s_edge : s_mid;
+      const T ma = sqrt(ar * ar + ai * ai) * sc;
+      const T mb = sqrt(br * br + bi * bi) * sc;
+      arow[k] = ma;
+      if (k2 != k) arow[k2] = mb;
+      if (two_sided && k != 0) {  // X[N-k] = conj X[k]
+        arow[2 * M - k] = ma;
+        if (k2 != k) arow[2 * M - k2] = mb;
+      }
+      if (prow) {
+        const T pa = atan2(ai, ar), pb = atan2(bi, br);
+        prow[k] = pa;
+        if (k2 != k) prow[k2] = pb;
+        if (two_sided && k != 0) {
+          prow[2 * M - k] = atan2(-ai, ar);
+          if (k2 != k) prow[2 * M - k2] = atan2(-bi, br);
+        }
+      }
+    }
+  });
 }
 
 // ---- element-wise kernels (stand-alone applyWindow / magnitude / phase) -----

@@ -1,0 +1,115 @@
+"""Fused spectrum kernel (pdsp_spectrum_f32) vs the f64 oracle's row-by-row spectrum():
+every size, every window, one-/two-sided, phase, peak, zero-padding, truncation,
+unaligned rows.  Covers both device paths: the packed-real kernel (N >= 64) and the
+complex fallback (N < 64 or an unaligned window)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def wrap(d):
+    return np.abs((d + np.pi) % (2 * np.pi) - np.pi)
+
+
+def run(plan, x, window, sides, **kw):
+    import torch
+    amp, ph, pk = plan.spectrum(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda(), window, sides, **kw)
+    torch.cuda.synchronize()
+    return (amp.cpu().numpy().astype(np.float64), None if ph is None else ph.cpu().numpy().astype(np.float64),
+            None if pk is None else pk.cpu().numpy())
+
+
+@pytest.mark.parametrize("log2n", list(range(0, 15)))
+@pytest.mark.parametrize("sides", ["one", "two"])
+def test_amplitude_phase_all_sizes(oracle_mod, log2n, sides):
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 1 << log2n
+    rng = np.random.default_rng(300 + log2n)
+    batch = 19 if n <= 4096 else 3
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    plan = BatchedFft(n, "cuda:0")
+    window = ["rect", "hann", "hamming", "blackman"][log2n % 4]
+    amp, ph, pk = run(plan, x, window, sides, want_phase=True, want_peak=True)
+    win = oracle_mod.create_window(window, n).astype(np.float32) if (window != "rect" and n > 1) else None
+    wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, two_sided=(sides == "two"),
+                                                       want_phase=True, want_peak=True)
+    assert amp.shape == wamp.shape
+    assert rel_err(amp, wamp) <= TOL
+    # phase only where the bin is well above the f32 noise floor
+    mask = wamp > 1e-3 * wamp.max(axis=-1, keepdims=True)
+    assert wrap(ph - wph)[mask].max(initial=0) <= 2e-3
+    for b in range(batch):  # peak: same bin, or a bin whose amplitude ties within tolerance
+        assert abs(wamp[b, pk[b]] - wamp[b, wpk[b]]) <= 2 * TOL * wamp[b].max()
+        assert (pk[b] >= 1) or wamp[b, 1:].max(initial=0) == 0
+
+
+@pytest.mark.parametrize("n,length", [(1024, 1000), (1024, 777), (1024, 1), (4096, 4095), (256, 300), (64, 64), (16384, 10001)])
+def test_zero_padding_and_truncation(oracle_mod, n, length):
+    from pragma_dsp_amd.batch import BatchedFft
+    rng = np.random.default_rng(n + length)
+    x = rng.standard_normal((5, length)).astype(np.float32)  # odd lengths => unaligned rows (VEC2 off)
+    plan = BatchedFft(n, "cuda:0")
+    amp, _, _ = run(plan, x, "hann", "one")
+    frame = np.zeros((5, n), dtype=np.float32)
+    frame[:, :min(n, length)] = x[:, :n]
+    wamp, _, _ = oracle_mod.Plan(n).spectrum_batch(frame, window=oracle_mod.create_window("hann", n).astype(np.float32))
+    assert rel_err(amp, wamp) <= TOL
+
+
+def test_custom_and_unaligned_window(oracle_mod):
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 2048
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((7, n)).astype(np.float32)
+    w = rng.random(n + 1).astype(np.float32)
+    plan = BatchedFft(n, "cuda:0")
+    dw = torch.from_numpy(w).cuda()
+    for off in (0, 1):  # offset 1 => 4-byte aligned only => complex fallback kernel
+        win = dw[off:off + n]
+        amp, _, _ = plan.spectrum(torch.from_numpy(x).cuda(), win, "one")
+        wamp, _, _ = oracle_mod.Plan(n).spectrum_batch(x, window=w[off:off + n])
+        assert rel_err(amp.cpu().numpy(), wamp) <= TOL
+
+
+def test_exact_zero_and_dc_semantics(oracle_mod, reallife):
+    """spectrum() of zeros is exactly 0 with peak 0 (edge_cases.test.ts:22-38); pure DC
+    leaves the peak at bin 0 (scaling.test.ts:185-201); DC + sine skips DC."""
+    from pragma_dsp_amd.batch import BatchedFft
+    plan = BatchedFft(1024, "cuda:0")
+    x = np.stack([reallife["zeros/signal"], reallife["dc_level1/signal"], reallife["dc_plus_sine_bin8/signal"],
+                  reallife["nyquist/signal"], reallife["impulse_pos0/signal"], reallife["sine_bin8_amp1.0/signal"]])
+    amp, _, pk = run(plan, x, "rect", "one", want_peak=True)
+    assert not amp[0].any() and pk[0] == 0
+    assert pk[1] == 0 and abs(amp[1, 0] - 1) < 1e-6 and np.abs(amp[1, 1:]).max() < 1e-6
+    assert pk[2] == 8
+    assert pk[3] == 512 and abs(amp[3, 512] - 1) < 1e-6          # Nyquist not doubled
+    assert np.abs(amp[4, 1:512] - 2 / 1024).max() < 1e-8          # impulse: flat
+    assert pk[5] == 8 and abs(amp[5, 8] - 1) < 1e-5
+    amp2, _, pk2 = run(plan, x, "rect", "two", want_peak=True)
+    assert pk2[5] == 8 and abs(amp2[5, 8] - 0.5) < 1e-5 and abs(amp2[5, 1016] - 0.5) < 1e-5
+    assert amp2.shape == (6, 1024)
+
+
+def test_spectrum_full_size_properties():
+    """Size-independent checks at a BASELINE-sized chunk (N=16384 x 4096 frames):
+    Parseval on the one-sided amplitudes, and linearity in the input scale."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n, b = 16384, 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1337)
+    x = torch.randn((b, n), generator=g, device="cuda", dtype=torch.float32)
+    plan = BatchedFft(n, "cuda:0")
+    amp, _, _ = plan.spectrum(x, "rect", "one")
+    a = amp.double()
+    # sum |X_k|^2 over all N bins = N * sum x^2 ; one-sided amp: |X0|/N, 2|Xk|/N, |X_{N/2}|/N
+    energy = (a[:, 0] ** 2 + a[:, -1] ** 2 + 0.5 * (a[:, 1:-1] ** 2).sum(dim=1)) * n
+    want = (x.double() ** 2).sum(dim=1)
+    assert float(((energy - want).abs() / want).max()) < 1e-5
+    amp3, _, _ = plan.spectrum(3 * x, "rect", "one")
+    assert float(((amp3 - 3 * amp).abs().amax(dim=1) / amp3.amax(dim=1)).max()) < 1e-6

@@ -77,7 +77,77 @@ struct StoreComplexNT {
   }
 };
 
+static void fill_tw(int log2n, std::vector<float2> &tw) {
+  const pdsp::RadixPlan p = pdsp::make_radix_plan(log2n);
+  tw.assign(p.twcount > 0 ? p.twcount : 1, make_float2(1, 0));
+  for (int i = 0; i < p.np; ++i) {
+    if (p.ns[i] <= 1) continue;
+    for (int r = 1; r < p.r[i]; ++r)
+      for (int k = 0; k < p.ns[i]; ++k) {
+        const double ang = -2.0 * M_PI * r * k / ((double)p.ns[i] * p.r[i]);
+        tw[p.twoff[i] + (r - 1) * p.ns[i] + k] = make_float2((float)cos(ang), (float)sin(ang));
+      }
+  }
+}
+
+// N=16384 fused spectrum (configs[3]) on a chunk of frames
+static int spec_main(long long frames, int rounds) {
+  const int n = 16384, m = n / 2, bins = m + 1;
+  float *x, *amp, *win;
+  CK(hipMalloc(&x, (size_t)frames * n * 4));
+  CK(hipMalloc(&amp, (size_t)frames * bins * 4));
+  CK(hipMalloc(&win, n * 4));
+  {
+    std::vector<float> h((size_t)frames * n);
+    unsigned s = 777;
+    for (auto &v : h) {
+      s = s * 1664525u + 1013904223u;
+      v = ((s >> 8) & 0xffff) / 32768.0f - 1.0f;
+    }
+    CK(hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> w(n);
+    for (int i = 0; i < n; ++i) w[i] = (float)(0.5 * (1 - cos(2 * M_PI * i / (n - 1))));
+    CK(hipMemcpy(win, w.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<float2> tw, twr(m / 2 + 1);
+  fill_tw(13, tw);
+  for (int k = 0; k <= m / 2; ++k) twr[k] = make_float2((float)cos(-2 * M_PI * k / n), (float)sin(-2 * M_PI * k / n));
+  float2 *dtw, *dtwr;
+  CK(hipMalloc(&dtw, tw.size() * 8));
+  CK(hipMemcpy(dtw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dtwr, twr.size() * 8));
+  CK(hipMemcpy(dtwr, twr.data(), twr.size() * 8, hipMemcpyHostToDevice));
+  using TR = pdsp::FftTraits<13>;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> ms;
+  auto run = [&] {
+    hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
+                       dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
+                       1.0f / n, 2.0f / n, frames);
+  };
+  for (int i = 0; i < 20; ++i) run();
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) run();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    ms.push_back(t / 5);
+  }
+  CK(hipGetLastError());
+  std::sort(ms.begin(), ms.end());
+  const double bytes = (4.0 * n + 4.0 * bins) * frames;
+  printf("spectrum16k exp=%d frames=%lld  med %.4f ms  min %.4f ms  med %.1f GB/s  max %.1f GB/s\n", PDSP_EXPERIMENT,
+         frames, ms[ms.size() / 2], ms[0], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 3 && std::string(argv[3]) == "spec") return spec_main(atoll(argv[1]), atoi(argv[2]));
   const int n = 4096;
   const long long batch = argc > 1 ? atoll(argv[1]) : 65536;
   const int rounds = argc > 2 ? atoi(argv[2]) : 10;
