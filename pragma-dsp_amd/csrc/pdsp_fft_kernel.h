@@ -128,20 +128,47 @@ struct FftTraits {
 };
 
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
+// pad(a + c) == pad(a) + cpad(c) when c is a multiple of 16 (or a is and c < 16)
+constexpr int cpad(int c) { return c + c / 16; }
+
+// A transform owned by >= 64 threads has one row per wave: tell the compiler the row
+// is wave-uniform so row bases live in SGPRs (batch < 2^31 is checked on the host).
+template <int TP>
+__device__ __forceinline__ long long uniform_row(long long row) {
+  if constexpr (TP >= 64) return (long long)__builtin_amdgcn_readfirstlane((int)row);
+  else return row;
+}
+
+// Streamed rows are touched exactly once: non-temporal loads/stores keep them from
+// displacing the twiddle/window tables in L2 (+4..10 % on the row-pattern copy and on
+// the C2C kernel, tools/kbench).
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void st_stream(T v, T *p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ float2 ld_stream2(const float2 *p) {
+  const double d = __builtin_nontemporal_load(reinterpret_cast<const double *>(p));  // one 8-byte nt load
+  float2 r;
+  __builtin_memcpy(&r, &d, sizeof(r));
+  return r;
+}
 
 // ---- load / store policies ------------------------------------------------
-// ld(row, i, re, im): fetch point i of row `row` (row is always < batch).
-// st(row, i, re, im): write point i.
+// ld(row, off, lane, re, im): fetch point off + lane of row `row` (row < batch).
+// st(row, off, lane, re, im): write point off + lane.
+// `row` and `off` are wave-uniform whenever a transform spans whole waves, so
+// `base + row*N + off` stays in SGPRs and the only per-lane address register is
+// `lane` (global_load ... v_lane, s[base:base+1] offset:imm).
 
 template <typename T>
 struct LoadComplex {  // forwardComplex / inverse (planes swapped by the caller)
   const T *__restrict__ re;
   const T *__restrict__ im;
   long long n;
-  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
-    const size_t o = (size_t)row * (size_t)n + (size_t)i;
-    a = re[o];
-    b = im[o];
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, T &a, T &b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)off;
+    a = ld_stream(re + o + (unsigned)lane);
+    b = ld_stream(im + o + (unsigned)lane);
   }
 };
 
@@ -149,8 +176,8 @@ template <typename T>
 struct LoadReal {  // Radix2Fft.forward: imaginary part is zero
   const T *__restrict__ re;
   long long n;
-  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
-    a = re[(size_t)row * (size_t)n + (size_t)i];
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, T &a, T &b) const {
+    a = ld_stream(re + (size_t)row * (size_t)n + (size_t)off + (unsigned)lane);
     b = T(0);
   }
 };
@@ -163,9 +190,10 @@ struct LoadFrameWindowed {  // buildFrame + applyWindow, spectrum.ts:36-43, :116
   const T *__restrict__ win;  // N values when HAS_WIN (rect otherwise)
   long long frame_len;        // 1 <= samples used per row <= N; the rest reads as zero
   long long stride;
-  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, T &a, T &b) const {
+    const int i = off + lane;
     const int last = (int)frame_len - 1;
-    T v = x[(size_t)row * (size_t)stride + (size_t)(i < last ? i : last)];
+    T v = ld_stream(x + (size_t)row * (size_t)stride + (unsigned)(i < last ? i : last));
     v = i <= last ? v : T(0);
     if constexpr (HAS_WIN) v *= win[i];
     a = v;
@@ -179,10 +207,10 @@ struct StoreComplex {
   T *__restrict__ im;
   long long n;
   T scale;  // 1 forward, 1/N inverse (fft.ts:142-148); power of two => exact
-  __device__ __forceinline__ void operator()(long long row, int i, T a, T b) const {
-    const size_t o = (size_t)row * (size_t)n + (size_t)i;
-    re[o] = a * scale;
-    im[o] = b * scale;
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, T a, T b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)off;
+    st_stream(a * scale, re + o + (unsigned)lane);
+    st_stream(b * scale, im + o + (unsigned)lane);
   }
 };
 
@@ -194,13 +222,27 @@ struct StoreAmplitude {  // magnitude + scaleAmplitude{One,Two}Sided [+ phase]
   int nyq;             // N/2 for one-sided (that bin is not doubled), -1 for two-sided
   T s_edge;            // 1/N
   T s_mid;             // 2/N one-sided, 1/N two-sided
-  __device__ __forceinline__ void operator()(long long row, int i, T a, T b) const {
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, T a, T b) const {
+    const int i = off + lane;
     if (i < bins) {
-      const size_t o = (size_t)row * (size_t)bins + (size_t)i;
+      const size_t o = (size_t)row * (size_t)bins;
       const T m = sqrt(a * a + b * b);
-      amp[o] = m * ((i == 0 || i == nyq) ? s_edge : s_mid);
-      if (ph) ph[o] = atan2(b, a);
+      st_stream(m * ((i == 0 || i == nyq) ? s_edge : s_mid), amp + o + (unsigned)i);
+      if (ph) st_stream(T(atan2(b, a)), ph + o + (unsigned)i);
     }
+  }
+};
+
+// ---- twiddle providers ---------------------------------------------------------
+
+// Reads W_{Ns*R}^{r*k} from the host-built table (layout: pdsp_radix.h), every use.
+template <typename T, int LOG2N>
+struct TableTwiddles {
+  const typename vec2<T>::type *__restrict__ tw;
+  template <int p, int r, int b>
+  __device__ __forceinline__ typename vec2<T>::type get(const int j) const {
+    constexpr int Ns = FftTraits<LOG2N>::P.ns[p];
+    return tw[FftTraits<LOG2N>::P.twoff[p] + (r - 1) * Ns + (j & (Ns - 1))];
   }
 };
 
@@ -211,13 +253,18 @@ struct StoreAmplitude {  // magnitude + scaleAmplitude{One,Two}Sided [+ phase]
 // registers, X[tid + TP*q] in slot q.  LAST_TO_LDS = true: the last pass also
 // scatters to LDS, in natural order (X[k] at lds_pad(k)), for a consumer that needs
 // other threads' bins; the caller must __syncthreads() before reading it.
-template <typename T, int LOG2N, bool LAST_TO_LDS>
+//
+// TWF supplies the inter-pass twiddles: twf.template get<p, r, b>(j) = W_{Ns*R}^{r*(j mod Ns)}
+// for input r of butterfly j = tid + b*TP of pass p.
+template <typename T, int LOG2N, bool LAST_TO_LDS, class TWF>
 __device__ __forceinline__ void fft_passes(T (&xr)[FftTraits<LOG2N>::E], T (&xi)[FftTraits<LOG2N>::E],
-                                           typename vec2<T>::type *const lrow,
-                                           const typename vec2<T>::type *__restrict__ tw, const int tid) {
+                                           typename vec2<T>::type *const lrow, const TWF &twf, const int tid) {
   using TR = FftTraits<LOG2N>;
   using T2 = typename vec2<T>::type;
   constexpr int E = TR::E, TP = TR::TP, NP = TR::NP;
+  // For N >= 256 every LDS address is (a thread-only base) + (a compile-time offset),
+  // so there is one address register per pass instead of one per element.
+  constexpr bool kConstOffsets = (TP % 16 == 0);
 
   static_for<NP>([&](auto pc) {
     constexpr int p = pc;
@@ -234,7 +281,6 @@ __device__ __forceinline__ void fft_passes(T (&xr)[FftTraits<LOG2N>::E], T (&xi)
       });
       const int j = tid + b * TP;  // butterfly index within the pass, 0 <= j < N/R
       if constexpr (Ns > 1) {
-        const T2 *const twp = tw + TR::P.twoff[p] + (j & (Ns - 1));
         static_for<R - 1>([&](auto rc) {
           constexpr int r = rc + 1;
           T2 w;
@@ -242,7 +288,7 @@ __device__ __forceinline__ void fft_passes(T (&xr)[FftTraits<LOG2N>::E], T (&xi)
             w.x = T(0.999) + T(r) * T(1e-4);
             w.y = T(0.03);
           } else {
-            w = twp[(r - 1) * Ns];
+            w = twf.template get<p, r, b>(j);
           }
           const T a = ar[r], c = ai[r];
           ar[r] = a * w.x - c * w.y;
@@ -258,23 +304,45 @@ __device__ __forceinline__ void fft_passes(T (&xr)[FftTraits<LOG2N>::E], T (&xi)
         });
       } else {
         // autosort scatter; for the last pass (Ns*R == N) this is the natural order
-        const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
-        static_for<R>([&](auto rc) {
-          T2 v;
-          v.x = ar[bitrev(rc, LR)];
-          v.y = ai[bitrev(rc, LR)];
-          lrow[lds_pad(j0 + rc * Ns)] = v;
-        });
+        if constexpr (kConstOffsets && (Ns % 16 == 0 || (Ns == 1 && R == 16))) {
+          // j = tid + b*TP: the part of the index that depends on b and rc is constant
+          constexpr int cb = Ns <= TP ? b * TP * R : b * TP;
+          const int j0t = Ns <= TP ? ((tid >> ilog2(Ns)) << ilog2(Ns * R)) + (tid & (Ns - 1)) : tid;
+          T2 *const wbase = lrow + lds_pad(j0t);
+          static_for<R>([&](auto rc) {
+            T2 v;
+            v.x = ar[bitrev(rc, LR)];
+            v.y = ai[bitrev(rc, LR)];
+            wbase[Ns == 1 ? cpad(cb) + rc : cpad(cb + rc * Ns)] = v;
+          });
+        } else {
+          const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
+          static_for<R>([&](auto rc) {
+            T2 v;
+            v.x = ar[bitrev(rc, LR)];
+            v.y = ai[bitrev(rc, LR)];
+            lrow[lds_pad(j0 + rc * Ns)] = v;
+          });
+        }
       }
     });
 
     if constexpr (!last) {
       __syncthreads();
-      static_for<E>([&](auto q) {
-        const T2 v = lrow[lds_pad(tid + TP * q)];
-        xr[q] = v.x;
-        xi[q] = v.y;
-      });
+      if constexpr (kConstOffsets) {
+        const T2 *const rbase = lrow + lds_pad(tid);
+        static_for<E>([&](auto q) {
+          const T2 v = rbase[cpad(TP * q)];
+          xr[q] = v.x;
+          xi[q] = v.y;
+        });
+      } else {
+        static_for<E>([&](auto q) {
+          const T2 v = lrow[lds_pad(tid + TP * q)];
+          xr[q] = v.x;
+          xi[q] = v.y;
+        });
+      }
       // the next pass writes LDS again (every pass but a register-resident last one)
       if constexpr (p + 1 < NP - 1 || LAST_TO_LDS) __syncthreads();
     }
@@ -299,14 +367,14 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
   const bool live = row_raw < batch;
   // dead rows of the last workgroup recompute the last live row and skip the
   // store, so that every thread reaches every barrier without predicated loads
-  const long long row = live ? row_raw : batch - 1;
+  const long long row = uniform_row<TP>(live ? row_raw : batch - 1);
   T2 *const lrow = lds + (NP > 1 ? rloc * TR::LROW : 0);
 
   T xr[E], xi[E];
-  static_for<E>([&](auto q) { ld(row, tid + TP * q, xr[q], xi[q]); });
-  fft_passes<T, LOG2N, false>(xr, xi, lrow, tw, tid);
+  static_for<E>([&](auto q) { ld(row, TP * q, tid, xr[q], xi[q]); });
+  fft_passes<T, LOG2N, false>(xr, xi, lrow, TableTwiddles<T, LOG2N>{tw}, tid);
   if (live) {
-    static_for<E>([&](auto q) { st(row, tid + TP * q, xr[q], xi[q]); });
+    static_for<E>([&](auto q) { st(row, TP * q, tid, xr[q], xi[q]); });
   }
 }
 
@@ -337,7 +405,7 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   const int rloc = (int)(threadIdx.x / TP);
   const long long row_raw = (long long)blockIdx.x * TR::ROWS + rloc;
   const bool live = row_raw < batch;
-  const long long row = live ? row_raw : batch - 1;
+  const long long row = uniform_row<TP>(live ? row_raw : batch - 1);
   T2 *const lrow = lds + rloc * TR::LROW;
 
   // buildFrame + applyWindow (spectrum.ts:36-43, :116-119) on load.  Unconditional
@@ -351,17 +419,17 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     T a, b;
     if constexpr (VEC2) {
       const int c = i0 < flen - 2 ? i0 : flen - 2;
-      const T2 v = *reinterpret_cast<const T2 *>(x + c);
+      const T2 v = ld_stream2(reinterpret_cast<const T2 *>(x + (unsigned)c));
       a = i0 < flen ? v.x : T(0);
       b = i0 < flen ? v.y : T(0);
     } else {
       const int c0 = i0 < flen - 1 ? i0 : flen - 1, c1 = i0 + 1 < flen - 1 ? i0 + 1 : flen - 1;
-      const T v0 = x[c0], v1 = x[c1];
+      const T v0 = ld_stream(x + (unsigned)c0), v1 = ld_stream(x + (unsigned)c1);
       a = i0 < flen ? v0 : T(0);
       b = i0 + 1 < flen ? v1 : T(0);
     }
     if constexpr (HAS_WIN && !(kExp & 2)) {
-      const T2 w = *reinterpret_cast<const T2 *>(win + i0);
+      const T2 w = *reinterpret_cast<const T2 *>(win + (unsigned)i0);
       a *= w.x;
       b *= w.y;
     }
@@ -369,7 +437,7 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     xi[q] = b;
   });
 
-  fft_passes<T, LOG2M, true>(xr, xi, lrow, tw, tid);
+  fft_passes<T, LOG2M, true>(xr, xi, lrow, TableTwiddles<T, LOG2M>{tw}, tid);
   __syncthreads();
 
   if (!live) return;
@@ -406,19 +474,18 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       const T sc = (k == 0) ? s_edge : s_mid;
       const T ma = sqrt(ar * ar + ai * ai) * sc;
       const T mb = sqrt(br * br + bi * bi) * sc;
-      arow[k] = ma;
-      if (k2 != k) arow[k2] = mb;
+      st_stream(ma, arow + k);
+      if (k2 != k) st_stream(mb, arow + k2);
       if (two_sided && k != 0) {  // X[N-k] = conj X[k]
-        arow[2 * M - k] = ma;
-        if (k2 != k) arow[2 * M - k2] = mb;
+        st_stream(ma, arow + (2 * M - k));
+        if (k2 != k) st_stream(mb, arow + (2 * M - k2));
       }
       if (prow) {
-        const T pa = atan2(ai, ar), pb = atan2(bi, br);
-        prow[k] = pa;
-        if (k2 != k) prow[k2] = pb;
+        st_stream(T(atan2(ai, ar)), prow + k);
+        if (k2 != k) st_stream(T(atan2(bi, br)), prow + k2);
         if (two_sided && k != 0) {
-          prow[2 * M - k] = atan2(-ai, ar);
-          if (k2 != k) prow[2 * M - k2] = atan2(-bi, br);
+          st_stream(T(atan2(-ai, ar)), prow + (2 * M - k));
+          if (k2 != k) st_stream(T(atan2(-bi, br)), prow + (2 * M - k2));
         }
       }
     }

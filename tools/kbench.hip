@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pdsp_fft_kernel.h"
+#include "pdsp_fft_stream.h"
 
 #define CK(x)                                                                       \
   do {                                                                              \
@@ -58,10 +59,10 @@ struct LoadComplexNT {
   const T *__restrict__ re;
   const T *__restrict__ im;
   long long n;
-  __device__ __forceinline__ void operator()(long long row, int i, T &a, T &b) const {
-    const size_t o = (size_t)row * (size_t)n + (size_t)i;
-    a = __builtin_nontemporal_load(re + o);
-    b = __builtin_nontemporal_load(im + o);
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, T &a, T &b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)off;
+    a = __builtin_nontemporal_load(re + o + (unsigned)lane);
+    b = __builtin_nontemporal_load(im + o + (unsigned)lane);
   }
 };
 template <typename T>
@@ -70,10 +71,10 @@ struct StoreComplexNT {
   T *__restrict__ im;
   long long n;
   T scale;
-  __device__ __forceinline__ void operator()(long long row, int i, T a, T b) const {
-    const size_t o = (size_t)row * (size_t)n + (size_t)i;
-    __builtin_nontemporal_store(a * scale, re + o);
-    __builtin_nontemporal_store(b * scale, im + o);
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, T a, T b) const {
+    const size_t o = (size_t)row * (size_t)n + (size_t)off;
+    __builtin_nontemporal_store(a * scale, re + o + (unsigned)lane);
+    __builtin_nontemporal_store(b * scale, im + o + (unsigned)lane);
   }
 };
 
@@ -122,10 +123,20 @@ static int spec_main(long long frames, int rounds) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<float> ms;
+  int cus = 256, per_cu = 1;
+  CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+  auto sk = pdsp::spectrum_stream_kernel<float, 13, true, false>;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sk, TR::WG, 0));
+  const bool stream = getenv("KB_STREAM") != nullptr;
+  printf("stream=%d occupancy %d WG/CU x %d CUs\n", (int)stream, per_cu, cus);
   auto run = [&] {
-    hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
-                       dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
-                       1.0f / n, 2.0f / n, frames);
+    if (stream)
+      hipLaunchKernelGGL(sk, dim3(std::min<long long>(frames, (long long)per_cu * cus)), dim3(TR::WG), 0, 0, x, win,
+                         (long long)n, dtw, dtwr, amp, (float *)nullptr, 0, 1.0f / n, 2.0f / n, frames);
+    else
+      hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
+                         dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
+                         1.0f / n, 2.0f / n, frames);
   };
   for (int i = 0; i < 20; ++i) run();
   CK(hipDeviceSynchronize());
