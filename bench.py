@@ -126,11 +126,16 @@ def main() -> int:
     dev = torch.device("cuda", local)
 
     from pragma_dsp_amd.batch import BatchedFft
+    from pragma_dsp_amd.shard import gather_rows, max_over_ranks, my_rows
 
     if args.workload == "spectrum16k":
         n, per_gpu = 16384, args.batch or (1 << 20)
     else:
         n, per_gpu = 4096, args.batch or 65536
+    # weak scaling: the global batch is per_gpu x world rows, split contiguously by rank
+    # (pragma-dsp_amd/shard.py); no collective on the data path
+    row0, row1 = my_rows(per_gpu * world, rank, world)
+    assert row1 - row0 == per_gpu
     plan = BatchedFft(n, dev)
     stream = torch.cuda.current_stream(dev)
 
@@ -198,26 +203,24 @@ def main() -> int:
     barrier()
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dev)
 
     gather = None
     if args.gather and world > 1 and args.workload != "spectrum16k":
-        import torch.distributed as dist
-        slab = torch.stack([ore, oim])  # [2][B][N] local output slab
-        full = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=dev)
-        dist.all_gather_into_tensor(full, slab)  # warm-up (communicator setup)
+        # the one exchange step of the path: RCCL all-gather of the output slabs,
+        # timed on its own -- at 2 GiB/rank it is xGMI-per-link bound and dwarfs the compute
+        gather_rows(ore, per_gpu * world)  # warm-up (communicator setup)
         barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(full, slab)
+        full_re = gather_rows(ore, per_gpu * world)
+        full_im = gather_rows(oim, per_gpu * world)
         torch.cuda.synchronize(dev)
-        gsec = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
-        dist.all_reduce(gsec, op=dist.ReduceOp.MAX)
-        gather = {"ms": float(gsec.item()) * 1e3, "bytes_per_rank": slab.numel() * 4,
-                  "GBps_in_per_gpu": slab.numel() * 4 * (world - 1) / float(gsec.item()) / 1e9}
+        gsec = max_over_ranks(time.perf_counter() - g0, dev)
+        nbytes = (ore.numel() + oim.numel()) * 4
+        gather = {"ms": gsec * 1e3, "bytes_per_rank": nbytes,
+                  "GBps_in_per_gpu": nbytes * (world - 1) / gsec / 1e9,
+                  "rows_gathered": int(full_re.shape[0])}
+        del full_re, full_im
 
     if rank == 0:
         samples_per_step = per_gpu * n * world

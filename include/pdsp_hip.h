@@ -81,11 +81,6 @@ PDSP_API int pdsp_version(void);
 PDSP_API const char *pdsp_last_error(void);
 /* Number of visible HIP devices (0 when there is none); never fails. */
 PDSP_API int pdsp_device_count(void);
-/* Tuning switch (process-wide): 1 (default) = pdsp_spectrum_f32 on whole, aligned frames
- * of N >= 2048 runs on the persistent streaming kernel (next-row prefetch,
- * register-resident twiddles); 0 = always the one-row-per-workgroup kernels.  Same
- * results within rounding; returns the old value. */
-PDSP_API int pdsp_set_streaming(int enabled);
 /* Largest N the single-pass kernels take for 4-byte / 8-byte scalars. */
 PDSP_API int pdsp_max_size(int scalar_bytes);
 

@@ -55,7 +55,6 @@ def _load() -> C.CDLL:
         "pdsp_last_error": ([], C.c_char_p),
         "pdsp_device_count": ([], i32),
         "pdsp_max_size": ([i32], i32),
-        "pdsp_set_streaming": ([i32], i32),
         "pdsp_is_pow2": ([ll], i32),
         "pdsp_next_pow2": ([ll], ll),
         "pdsp_window_make": ([i32, ll, dp], i32),

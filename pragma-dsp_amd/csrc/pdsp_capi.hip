@@ -17,14 +17,10 @@
 
 #include "../../include/pdsp_hip.h"
 #include "pdsp_fft_kernel.h"
-#include "pdsp_fft_stream.h"
 
 namespace {
 
 thread_local std::string g_err;
-// 1 = use the persistent streaming spectrum kernel where it applies (default); 0 = always
-// the one-row-per-workgroup kernels.  Both paths are parity-tested; see pdsp_set_streaming().
-int g_streaming = 1;
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -120,19 +116,6 @@ hipError_t launch_one(const LD &ld, const ST &st, const float2 *tw, long long ba
   return hipGetLastError();
 }
 
-// Persistent grid: as many workgroups as the chip keeps resident (occupancy x CUs),
-// never more than there are row groups.
-template <class K>
-unsigned persistent_grid(K kernel, int wg, long long ngroups) {
-  int dev = 0, cus = 256, per_cu = 1;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, wg, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  long long g = (long long)per_cu * cus;
-  if (g > ngroups) g = ngroups;
-  return (unsigned)(g < 1 ? 1 : g);
-}
-
 template <class LD, class ST>
 hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, long long batch, hipStream_t s) {
   switch (log2n) {
@@ -148,33 +131,12 @@ hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, l
 }
 
 template <int LOG2M>
-hipError_t launch_packed_one(bool vec2, bool full, const float *frames, const float *win, long long frame_len,
+hipError_t launch_packed_one(bool vec2, const float *frames, const float *win, long long frame_len,
                              long long stride, const float2 *tw, const float2 *twr, float *amp, float *ph,
                              int two_sided, float s_edge, float s_mid, long long batch, hipStream_t s) {
   using TR = pdsp::FftTraits<LOG2M>;
   const long long ngroups = (batch + TR::ROWS - 1) / TR::ROWS;
   const dim3 block(TR::WG);
-  if constexpr (LOG2M >= 10) {
-    // persistent kernel: whole, aligned frames only
-    if (g_streaming && vec2 && full) {
-      static thread_local unsigned full_grid[4] = {0, 0, 0, 0};
-      const bool general = two_sided || ph;
-      const int slot = (win ? 1 : 0) + (general ? 2 : 0);
-#define PDSP_STREAM(W, G)                                                                                        \
-  do {                                                                                                           \
-    auto k = pdsp::spectrum_stream_kernel<float, LOG2M, W, G>;                                                   \
-    if (!full_grid[slot]) full_grid[slot] = persistent_grid(k, TR::WG, 0x7fffffffLL);                            \
-    hipLaunchKernelGGL(k, dim3(ngroups < (long long)full_grid[slot] ? (unsigned)ngroups : full_grid[slot]), block, \
-                       0, s, frames, win, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, batch);            \
-  } while (0)
-      if (win && general) PDSP_STREAM(true, true);
-      else if (win) PDSP_STREAM(true, false);
-      else if (general) PDSP_STREAM(false, true);
-      else PDSP_STREAM(false, false);
-#undef PDSP_STREAM
-      return hipGetLastError();
-    }
-  }
 #define PDSP_LAUNCH(V, W)                                                                                       \
   hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, LOG2M, V, W>), dim3((unsigned)ngroups), block, 0, s, \
                      frames, win, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, batch)
@@ -290,12 +252,6 @@ int pdsp_device_count(void) {
     return 0;
   }
   return count;
-}
-
-int pdsp_set_streaming(int enabled) {
-  const int prev = g_streaming;
-  g_streaming = enabled ? 1 : 0;
-  return prev;
 }
 
 int pdsp_max_size(int scalar_bytes) {
@@ -530,7 +486,7 @@ int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch, const float *frame
   if (plan->d_tw32_half && (window == nullptr || ((uintptr_t)window & 7) == 0)) {
     // packed-real path: N/2-point complex transform + Hermitian split fused with the store
     const bool vec2 = ((uintptr_t)frames & 7) == 0 && (frame_stride & 1) == 0 && (used & 1) == 0;
-    PDSP_HIP_TRY(launch_packed(plan->log2n - 1, vec2, used == n, frames, window, used, frame_stride, plan->d_tw32_half,
+    PDSP_HIP_TRY(launch_packed(plan->log2n - 1, vec2, frames, window, used, frame_stride, plan->d_tw32_half,
                                plan->d_twr32, amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid, batch,
                                (hipStream_t)stream));
   } else {

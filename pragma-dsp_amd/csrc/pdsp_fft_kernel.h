@@ -153,6 +153,12 @@ __device__ __forceinline__ float2 ld_stream2(const float2 *p) {
   return r;
 }
 
+// |z| for the fused amplitude stores: one v_sqrt_f32 (1 ulp) instead of the ~10-instruction
+// correctly rounded sequence -- 17 of them per thread sit in the VALU-bound epilogue of the
+// N=16384 spectrum kernel.  1 ulp = 6e-8 relative, far inside the 1e-5 contract.
+__device__ __forceinline__ float mag2(float re, float im) { return __builtin_amdgcn_sqrtf(re * re + im * im); }
+__device__ __forceinline__ double mag2(double re, double im) { return sqrt(re * re + im * im); }
+
 // ---- load / store policies ------------------------------------------------
 // ld(row, off, lane, re, im): fetch point off + lane of row `row` (row < batch).
 // st(row, off, lane, re, im): write point off + lane.
@@ -226,7 +232,7 @@ struct StoreAmplitude {  // magnitude + scaleAmplitude{One,Two}Sided [+ phase]
     const int i = off + lane;
     if (i < bins) {
       const size_t o = (size_t)row * (size_t)bins;
-      const T m = sqrt(a * a + b * b);
+      const T m = mag2(a, b);
       st_stream(m * ((i == 0 || i == nyq) ? s_edge : s_mid), amp + o + (unsigned)i);
       if (ph) st_stream(T(atan2(b, a)), ph + o + (unsigned)i);
     }
@@ -472,8 +478,8 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       const int k2 = M - k;
       // bins 0 (DC, from k = 0) and M (Nyquist, the partner of k = 0) are not doubled
       const T sc = (k == 0) ? s_edge : s_mid;
-      const T ma = sqrt(ar * ar + ai * ai) * sc;
-      const T mb = sqrt(br * br + bi * bi) * sc;
+      const T ma = mag2(ar, ai) * sc;
+      const T mb = mag2(br, bi) * sc;
       st_stream(ma, arow + k);
       if (k2 != k) st_stream(mb, arow + k2);
       if (two_sided && k != 0) {  // X[N-k] = conj X[k]

@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "pdsp_fft_kernel.h"
-#include "pdsp_fft_stream.h"
+#include "experiments/pdsp_fft_stream.h"
 
 #define CK(x)                                                                       \
   do {                                                                              \
