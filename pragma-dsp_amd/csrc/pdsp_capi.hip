@@ -131,17 +131,17 @@ hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, l
 }
 
 template <int LOG2M>
-hipError_t launch_packed_one(bool vec2, const float *frames, const float *win, long long frame_len,
+hipError_t launch_packed_one(bool fast, const float *frames, const float *win, long long frame_len,
                              long long stride, const float2 *tw, const float2 *twr, float *amp, float *ph,
                              int two_sided, float s_edge, float s_mid, long long batch, hipStream_t s) {
   using TR = pdsp::FftTraits<LOG2M>;
   const long long ngroups = (batch + TR::ROWS - 1) / TR::ROWS;
   const dim3 block(TR::WG);
-#define PDSP_LAUNCH(V, W)                                                                                       \
-  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, LOG2M, V, W>), dim3((unsigned)ngroups), block, 0, s, \
+#define PDSP_LAUNCH(F, W)                                                                                       \
+  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, LOG2M, F, W>), dim3((unsigned)ngroups), block, 0, s, \
                      frames, win, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, batch)
-  if (vec2 && win) PDSP_LAUNCH(true, true);
-  else if (vec2) PDSP_LAUNCH(true, false);
+  if (fast && win) PDSP_LAUNCH(true, true);
+  else if (fast) PDSP_LAUNCH(true, false);
   else if (win) PDSP_LAUNCH(false, true);
   else PDSP_LAUNCH(false, false);
 #undef PDSP_LAUNCH
@@ -485,8 +485,10 @@ int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch, const float *frame
   const float s_edge = 1.0f / (float)n, s_mid = (sides == PDSP_SIDES_ONE ? 2.0f : 1.0f) / (float)n;
   if (plan->d_tw32_half && (window == nullptr || ((uintptr_t)window & 7) == 0)) {
     // packed-real path: N/2-point complex transform + Hermitian split fused with the store
-    const bool vec2 = ((uintptr_t)frames & 7) == 0 && (frame_stride & 1) == 0 && (used & 1) == 0;
-    PDSP_HIP_TRY(launch_packed(plan->log2n - 1, vec2, frames, window, used, frame_stride, plan->d_tw32_half,
+    // fast variant: whole 8-byte aligned frames, one-sided amplitude only (config 4's shape)
+    const bool fast = ((uintptr_t)frames & 7) == 0 && (frame_stride & 1) == 0 && used == n &&
+                      sides == PDSP_SIDES_ONE && phase_out == nullptr;
+    PDSP_HIP_TRY(launch_packed(plan->log2n - 1, fast, frames, window, used, frame_stride, plan->d_tw32_half,
                                plan->d_twr32, amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid, batch,
                                (hipStream_t)stream));
   } else {

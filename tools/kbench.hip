@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "pdsp_fft_kernel.h"
-#include "experiments/pdsp_fft_stream.h"
 
 #define CK(x)                                                                       \
   do {                                                                              \
@@ -53,30 +52,6 @@ __global__ void __launch_bounds__(256) copy_float4(const float4 *__restrict__ in
   const size_t step = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) out[i] = in[i];
 }
-
-template <typename T>
-struct LoadComplexNT {
-  const T *__restrict__ re;
-  const T *__restrict__ im;
-  long long n;
-  __device__ __forceinline__ void operator()(long long row, int off, int lane, T &a, T &b) const {
-    const size_t o = (size_t)row * (size_t)n + (size_t)off;
-    a = __builtin_nontemporal_load(re + o + (unsigned)lane);
-    b = __builtin_nontemporal_load(im + o + (unsigned)lane);
-  }
-};
-template <typename T>
-struct StoreComplexNT {
-  T *__restrict__ re;
-  T *__restrict__ im;
-  long long n;
-  T scale;
-  __device__ __forceinline__ void operator()(long long row, int off, int lane, T a, T b) const {
-    const size_t o = (size_t)row * (size_t)n + (size_t)off;
-    __builtin_nontemporal_store(a * scale, re + o + (unsigned)lane);
-    __builtin_nontemporal_store(b * scale, im + o + (unsigned)lane);
-  }
-};
 
 static void fill_tw(int log2n, std::vector<float2> &tw) {
   const pdsp::RadixPlan p = pdsp::make_radix_plan(log2n);
@@ -123,20 +98,10 @@ static int spec_main(long long frames, int rounds) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<float> ms;
-  int cus = 256, per_cu = 1;
-  CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-  auto sk = pdsp::spectrum_stream_kernel<float, 13, true, false>;
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sk, TR::WG, 0));
-  const bool stream = getenv("KB_STREAM") != nullptr;
-  printf("stream=%d occupancy %d WG/CU x %d CUs\n", (int)stream, per_cu, cus);
   auto run = [&] {
-    if (stream)
-      hipLaunchKernelGGL(sk, dim3(std::min<long long>(frames, (long long)per_cu * cus)), dim3(TR::WG), 0, 0, x, win,
-                         (long long)n, dtw, dtwr, amp, (float *)nullptr, 0, 1.0f / n, 2.0f / n, frames);
-    else
-      hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
-                         dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
-                         1.0f / n, 2.0f / n, frames);
+    hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
+                       dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
+                       1.0f / n, 2.0f / n, frames);
   };
   for (int i = 0; i < 20; ++i) run();
   CK(hipDeviceSynchronize());
@@ -152,8 +117,7 @@ static int spec_main(long long frames, int rounds) {
   CK(hipGetLastError());
   std::sort(ms.begin(), ms.end());
   const double bytes = (4.0 * n + 4.0 * bins) * frames;
-  printf("spectrum16k exp=%d frames=%lld  med %.4f ms  min %.4f ms  med %.1f GB/s  max %.1f GB/s\n", PDSP_EXPERIMENT,
-         frames, ms[ms.size() / 2], ms[0], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+  printf("spectrum16k frames=%lld  med %.4f ms  min %.4f ms  med %.1f GB/s  max %.1f GB/s\n", frames, ms[ms.size() / 2], ms[0], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
   return 0;
 }
 
@@ -220,25 +184,6 @@ int main(int argc, char **argv) {
                   hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
                                      dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
                 }});
-  vs.push_back({"fft_v1_nt", [&] {
-                  LoadComplexNT<float> ld{re, im, n};
-                  StoreComplexNT<float> st{ore, oim, n, 1.0f};
-                  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
-                                     dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
-                }});
-  vs.push_back({"fft_v1_ntload", [&] {
-                  LoadComplexNT<float> ld{re, im, n};
-                  pdsp::StoreComplex<float> st{ore, oim, n, 1.0f};
-                  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
-                                     dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
-                }});
-  vs.push_back({"fft_v1_ntstore", [&] {
-                  pdsp::LoadComplex<float> ld{re, im, n};
-                  StoreComplexNT<float> st{ore, oim, n, 1.0f};
-                  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, 12, decltype(ld), decltype(st)>),
-                                     dim3((batch + TR::ROWS - 1) / TR::ROWS), dim3(TR::WG), 0, 0, ld, st, dtw, batch);
-                }});
-
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
