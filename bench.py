@@ -98,12 +98,64 @@ def traffic_from_profile(kernel_substr: str):
     return None
 
 
+def single_frame_latency(args, dev) -> int:
+    """BASELINE configs[1]: ONE N=1024 real frame, Hann window, forward FFT, magnitude.
+    Latency-bound (8 KiB of traffic): reported as microseconds, not as a roofline fraction.
+      dropin_spectrum_us  spectrum(x, {fftSize:1024, window:'hann'}) host f64 in -> f64 out
+                          (f64->f32, H2D, fused kernel, D2H, f32->f64, peak search)
+      dropin_forward_us   FFT(1024).forward(x) host f64 in -> f64 out (plan reused)
+      kernel_us           the fused kernel alone on device-resident data (HIP events)"""
+    import pragma_dsp_amd as pd
+    from pragma_dsp_amd.batch import BatchedFft
+    n, iters = 1024, max(args.steps, 200)
+    idx = np.arange(n)
+    x = np.sin(2 * np.pi * 440.0 * idx / 48000.0)  # the reference's sine_440hz leakage case
+    opts = {"sampleRate": 48000, "fftSize": n, "window": "hann"}
+    fft = pd.FFT(n)
+    out = fft.createComplexArray()
+
+    def timed(fn):
+        for _ in range(20):
+            fn()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e6)
+        return float(np.median(ts)), float(np.min(ts))
+
+    spec_med, spec_min = timed(lambda: pd.spectrum(x, opts))
+    fwd_med, fwd_min = timed(lambda: fft.forward(x, out))
+    plan = BatchedFft(n, dev)
+    dx = torch.from_numpy(x.astype(np.float32)).to(dev).reshape(1, n)
+    amp = torch.empty((1, n // 2 + 1), dtype=torch.float32, device=dev)
+    for _ in range(20):
+        plan.spectrum(dx, "hann", "one", out=amp)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        plan.spectrum(dx, "hann", "one", out=amp)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    kernel_us = e0.elapsed_time(e1) * 1e3 / iters
+    print(json.dumps({
+        "metric": "single-frame latency (N=1024, Hann + FFT + magnitude)", "unit": "us", "higher_is_better": False,
+        "value": spec_med, "n_gpus": 1, "steps": iters, "warmup": 20, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "N=1024 single frame spectrum(), hann, one-sided (configs[1])"},
+        "dropin_spectrum_us": {"median": spec_med, "min": spec_min},
+        "dropin_forward_us": {"median": fwd_med, "min": fwd_min},
+        "kernel_back_to_back_us": kernel_us,
+    }), flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "spectrum16k"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "spectrum16k", "single1024"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,6 +179,9 @@ def main() -> int:
 
     from pragma_dsp_amd.batch import BatchedFft
     from pragma_dsp_amd.shard import gather_rows, max_over_ranks, my_rows
+
+    if args.workload == "single1024":
+        return single_frame_latency(args, dev)
 
     if args.workload == "spectrum16k":
         n, per_gpu = 16384, args.batch or (1 << 20)

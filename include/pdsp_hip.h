@@ -112,6 +112,10 @@ PDSP_API long long pdsp_find_peak_f64(const double *amplitude, long long bins);
 PDSP_API int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out);
 PDSP_API int pdsp_plan_destroy(pdsp_plan *plan);
 PDSP_API long long pdsp_plan_size(const pdsp_plan *plan);
+/* pdsp_spectrum_host_f64 keeps its plans and device windows in a process-wide cache keyed
+ * by (size, device) -- the FourierLive idea, src/effect/index.ts:30-48 (the reference's
+ * spectrum() rebuilds plan and window on every call, spectrum.ts:114-116).  This frees it. */
+PDSP_API int pdsp_plan_cache_clear(void);
 PDSP_API int pdsp_plan_device(const pdsp_plan *plan);
 
 /* ---- device-pointer batched transforms (f32) --------------------------- */

@@ -64,6 +64,7 @@ def _load() -> C.CDLL:
         "pdsp_plan_create": ([ll, i32, C.POINTER(vp)], i32),
         "pdsp_plan_destroy": ([vp], i32),
         "pdsp_plan_size": ([vp], ll),
+        "pdsp_plan_cache_clear": ([], i32),
         "pdsp_plan_device": ([vp], i32),
         "pdsp_fft_forward_real_f32": ([vp, ll, vp, vp, vp, vp], i32),
         "pdsp_fft_forward_complex_f32": ([vp, ll, vp, vp, vp, vp, vp], i32),

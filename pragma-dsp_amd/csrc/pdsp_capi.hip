@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -230,6 +231,57 @@ struct Scratch {
   }
 };
 
+// Plans for the one-shot host entry points, keyed by (size, device): the idea of
+// FourierLive's `Map<size, FFT>` and `Map<"type:size", window>` caches
+// (src/effect/index.ts:30-48).  The reference's spectrum() rebuilds both on every call
+// (spectrum.ts:114-116) -- its dominant one-shot cost; here a repeat call costs no table
+// build, no hipMalloc and no upload.  Leaked on purpose at exit (the HIP runtime may
+// already be gone when static destructors run); pdsp_plan_cache_clear() frees it.
+struct PlanCache {
+  std::mutex mu;
+  std::map<std::pair<long long, int>, pdsp_plan *> plans;
+};
+PlanCache &plan_cache() {
+  static PlanCache *c = new PlanCache();
+  return *c;
+}
+
+int cached_plan(long long n, pdsp_plan **out) {
+  int dev = 0;
+  PDSP_HIP_TRY(hipGetDevice(&dev));
+  PlanCache &c = plan_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  auto it = c.plans.find({n, dev});
+  if (it != c.plans.end()) {
+    *out = it->second;
+    return PDSP_OK;
+  }
+  pdsp_plan *p = nullptr;
+  if (int rc = pdsp_plan_create(n, dev, &p)) return rc;
+  c.plans[{n, dev}] = p;
+  *out = p;
+  return PDSP_OK;
+}
+
+// Device copy (f32) of createWindow(type, N), built once per plan.  Caller holds plan->mu.
+int plan_window(pdsp_plan *plan, int type, const float **out) {
+  if (!plan->d_win[type]) {
+    std::vector<double> w((size_t)plan->n);
+    if (int rc = pdsp_window_make(type, plan->n, w.data())) return rc;
+    std::vector<float> wf(w.begin(), w.end());
+    float *d = nullptr;
+    PDSP_HIP_TRY(hipMalloc((void **)&d, wf.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(d, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      PDSP_HIP_TRY(e);
+    }
+    plan->d_win[type] = d;
+  }
+  *out = plan->d_win[type];
+  return PDSP_OK;
+}
+
 int require_device() {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -375,6 +427,14 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
     return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) while uploading the twiddle table", (int)e, hipGetErrorString(e));
   }
   *plan_out = p;
+  return PDSP_OK;
+}
+
+int pdsp_plan_cache_clear(void) {
+  PlanCache &c = plan_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (auto &kv : c.plans) pdsp_plan_destroy(kv.second);
+  c.plans.clear();
   return PDSP_OK;
 }
 
@@ -601,31 +661,26 @@ int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_r
     return fail(PDSP_ERR_WINDOW_TYPE, "Unsupported window type: %d", window);
   if (sample_rate <= 0) return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
   if (!freq_out || !amp_out || !phase_out) return fail(PDSP_ERR_BAD_ARG, "null output");
+  if (int rc = require_device()) return rc;
   pdsp_plan *plan = nullptr;
-  if (int rc = pdsp_plan_create(n, -1, &plan)) return rc;
-  struct PlanDrop {
-    pdsp_plan *p;
-    ~PlanDrop() { pdsp_plan_destroy(p); }
-  } drop{plan};
+  if (int rc = cached_plan(n, &plan)) return rc;  // plan + window are cached per (size, device)
+  std::lock_guard<std::mutex> lk(plan->mu);
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
   const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
   const long long used = len < n ? len : n;
-  // staging: [frame n][window n][amp bins][phase bins]
+  // staging: [frame n][amp bins][phase bins]
   if (int rc = ensure_stage(plan, (size_t)(2 * n + 2 * bins))) return rc;
   float *h = plan->h_stage, *d = plan->d_stage;
   for (long long i = 0; i < used; ++i) h[i] = (float)samples[i];
   for (long long i = used; i < n; ++i) h[i] = 0.0f;
-  const bool has_win = (n != 1 && window != PDSP_WIN_RECT);
-  if (has_win) {
-    std::vector<double> w((size_t)n);
-    if (int rc = pdsp_window_make(window, n, w.data())) return rc;
-    for (long long i = 0; i < n; ++i) h[n + i] = (float)w[(size_t)i];
+  const float *d_window = nullptr;
+  if (n != 1 && window != PDSP_WIN_RECT) {
+    if (int rc = plan_window(plan, window, &d_window)) return rc;
   }
   hipStream_t s = plan->stream;
-  PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)(has_win ? 2 * n : n) * sizeof(float), hipMemcpyHostToDevice, s));
-  if (int rc = pdsp_spectrum_f32(plan, 1, d, n, n, has_win ? d + n : nullptr, sides, d + 2 * n, d + 2 * n + bins,
-                                 nullptr, s))
+  PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+  if (int rc = pdsp_spectrum_f32(plan, 1, d, n, n, d_window, sides, d + 2 * n, d + 2 * n + bins, nullptr, s))
     return rc;
   PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * n, d + 2 * n, (size_t)(2 * bins) * sizeof(float), hipMemcpyDeviceToHost, s));
   PDSP_HIP_TRY(hipStreamSynchronize(s));

@@ -1,0 +1,136 @@
+"""Size-independent properties at BASELINE.json's full size (N=4096 x 65,536 rows) and
+batch-shape edge cases, through the C ABI.  The oracle checks a 256-row random subset."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def full():
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n, b = 4096, 65536
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1337)
+    re = torch.randn((b, n), generator=g, device="cuda", dtype=torch.float32)
+    im = torch.randn((b, n), generator=g, device="cuda", dtype=torch.float32)
+    plan = BatchedFft(n, "cuda:0")
+    ore, oim = plan.forward(re, im)
+    torch.cuda.synchronize()
+    return plan, re, im, ore, oim
+
+
+def test_full_size_subset_vs_oracle(full, oracle_mod):
+    import torch
+    plan, re, im, ore, oim = full
+    rows = torch.from_numpy(np.random.default_rng(3).choice(65536, 256, replace=False)).cuda()
+    wre, wim = oracle_mod.Plan(4096).forward_complex(re[rows].cpu().numpy(), im[rows].cpu().numpy())
+    got = ore[rows].cpu().numpy().astype(np.float64) + 1j * oim[rows].cpu().numpy()
+    assert rel_err(got, wre + 1j * wim) <= TOL
+
+
+def test_full_size_parseval_and_round_trip(full):
+    import torch
+    plan, re, im, ore, oim = full
+    n = 4096
+    e_in = (re.double() ** 2 + im.double() ** 2).sum(dim=1)
+    e_out = (ore.double() ** 2 + oim.double() ** 2).sum(dim=1) / n
+    assert float(((e_out - e_in).abs() / e_in).max()) < 1e-5
+    bre, bim = plan.inverse(ore, oim)
+    scale = torch.maximum(re.abs().amax(dim=1), im.abs().amax(dim=1))
+    assert float(((bre - re).abs().amax(dim=1) / scale).max()) <= TOL
+    assert float(((bim - im).abs().amax(dim=1) / scale).max()) <= TOL
+
+
+def test_full_size_linearity_and_shift(full):
+    import torch
+    plan, re, im, ore, oim = full
+    half = 32768
+    a, b = 0.75, -1.25  # F(a x + b y) = a F(x) + b F(y)
+    sre, sim = plan.forward(a * re[:half] + b * re[half:], a * im[:half] + b * im[half:])
+    wre, wim = a * ore[:half] + b * ore[half:], a * oim[:half] + b * oim[half:]
+    scale = torch.maximum(wre.abs().amax(dim=1), wim.abs().amax(dim=1))
+    assert float(((sre - wre).abs().amax(dim=1) / scale).max()) <= TOL
+    assert float(((sim - wim).abs().amax(dim=1) / scale).max()) <= TOL
+    # a circular shift by one sample multiplies bin k by e^{-2 pi i k / N}
+    rows = slice(0, 512)
+    rre, rim = plan.forward(torch.roll(re[rows], 1, dims=1), torch.roll(im[rows], 1, dims=1))
+    k = torch.arange(4096, device="cuda", dtype=torch.float64)
+    c, s = torch.cos(2 * np.pi * k / 4096), -torch.sin(2 * np.pi * k / 4096)
+    ere = ore[rows].double() * c - oim[rows].double() * s
+    eim = ore[rows].double() * s + oim[rows].double() * c
+    sc = torch.maximum(ere.abs().amax(dim=1), eim.abs().amax(dim=1))
+    assert float(((rre.double() - ere).abs().amax(dim=1) / sc).max()) <= TOL
+    assert float(((rim.double() - eim).abs().amax(dim=1) / sc).max()) <= TOL
+
+
+def test_row_wise_in_place(full):
+    """Each workgroup loads its whole row before it stores, so out may alias in."""
+    import torch
+    plan, re, im, ore, oim = full
+    a, b = re[:1000].clone(), im[:1000].clone()
+    plan.forward(a, b, out=(a, b))
+    assert torch.equal(a, ore[:1000]) and torch.equal(b, oim[:1000])  # bit-identical to out-of-place
+
+
+@pytest.mark.parametrize("n", [8, 64, 256, 1024, 2048])
+@pytest.mark.parametrize("batch", [1, 2, 3, 5, 255, 257])
+def test_ragged_batches(oracle_mod, n, batch):
+    """Batches that do not fill the last workgroup (several rows share a workgroup for N < 4096)."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    rng = np.random.default_rng(n * 1000 + batch)
+    re = rng.standard_normal((batch, n)).astype(np.float32)
+    im = rng.standard_normal((batch, n)).astype(np.float32)
+    plan = BatchedFft(n, "cuda:0")
+    guard = torch.full((batch + 2, n), 777.0, device="cuda")  # canary rows around the output
+    ore = guard[1:batch + 1]
+    oim = torch.empty((batch, n), device="cuda")
+    plan.forward(torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda(), out=(ore, oim))
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    assert rel_err(ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy(), wre + 1j * wim) <= TOL
+    assert bool((guard[0] == 777.0).all()) and bool((guard[-1] == 777.0).all())  # nothing written out of range
+    amp, _, pk = plan.spectrum(torch.from_numpy(re).cuda(), "hann", "one", want_peak=True)
+    wamp, _, wpk = oracle_mod.Plan(n).spectrum_batch(re, window=oracle_mod.create_window("hann", n).astype(np.float32),
+                                                     want_peak=True)
+    assert rel_err(amp.cpu().numpy(), wamp) <= TOL
+
+
+def test_special_inputs_exact(oracle_mod):
+    """zeros -> exact zeros; impulse -> flat |X| = 1; DC -> only bin 0 (edge_cases / signals tests)."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    for n in (64, 1024, 4096, 16384):
+        plan = BatchedFft(n, "cuda:0")
+        x = torch.zeros((3, n), device="cuda")
+        x[1, 0] = 1.0
+        x[2, :] = 1.0
+        ore, oim = plan.forward(x)
+        assert not bool(ore[0].any()) and not bool(oim[0].any())
+        assert float((torch.sqrt(ore[1] ** 2 + oim[1] ** 2) - 1).abs().max()) < 1e-6
+        assert abs(float(ore[2, 0]) - n) < 1e-3 * n and float(ore[2, 1:].abs().max()) == 0.0 and not bool(oim[2].any())
+
+
+def test_error_paths_on_device(pdsp):
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    plan = BatchedFft(64, "cuda:0")
+    with pytest.raises(pdsp.PdspError, match="FFT input length 32 != size 64"):
+        plan.forward(torch.zeros((2, 32), device="cuda"))
+    with pytest.raises(pdsp.PdspError, match="Window length must match input length."):
+        plan.spectrum(torch.zeros((2, 64), device="cuda"), torch.ones(32, device="cuda"))
+    with pytest.raises(pdsp.PdspError, match="FFT size must be power of two, got 48"):
+        BatchedFft(48, "cuda:0")
+    with pytest.raises(pdsp.PdspError, match="FFT input length 5 != size 8"):
+        pdsp.Radix2Fft(8).forward([1, 2, 3, 4, 5])
+    with pytest.raises(pdsp.PdspError, match="exceeds the single-pass limit"):
+        pdsp.Radix2Fft(32768)
+    out = plan.forward(torch.zeros((0, 64), device="cuda"))  # empty batch: no launch
+    assert out[0].shape == (0, 64)
+    assert pdsp.lib.pdsp_plan_cache_clear() == 0
+    r = pdsp.spectrum([], {"sampleRate": 8})  # nextPowerOfTwo(0) = 1
+    assert len(r.amplitude) == 1 and r.amplitude[0] == 0 and r.peak.index == 0
