@@ -75,6 +75,13 @@ typedef struct pdsp_peak {      /* SpectrumPeak, src/public/spectrum.ts:15-20 */
   double phase;
 } pdsp_peak;
 
+typedef struct pdsp_peak32 {    /* SpectrumPeak of one frame as the device writes it (16 bytes) */
+  int32_t index;
+  float frequency;
+  float amplitude;
+  float phase;
+} pdsp_peak32;
+
 /* ---- library ---------------------------------------------------------- */
 
 PDSP_API int pdsp_version(void);
@@ -164,6 +171,22 @@ PDSP_API int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch,
                                const float *window, int sides,
                                float *amp_out, float *phase_out, int32_t *peak_out,
                                pdsp_stream stream);
+
+/* The whole tail of spectrum() on the device (src/public/spectrum.ts:116-134), one
+ * SpectrumPeak per frame: findPeak (:74-105: bins >= 1, strict '>', the first of equal
+ * values wins, bin 0 when no other bin is > 0) is fused into the spectrum kernel, with
+ * peak.frequency = index * sample_rate / N and peak.phase = atan2 of that bin.
+ *   peaks_out   [batch] records (16 B each).
+ *   amp_out / phase_out   optional [batch][bins] rows as in pdsp_spectrum_f32; NULL for
+ *               peaks-only output: HBM traffic is then 4 B/sample in + 16 B/frame out, and a
+ *               multi-GPU gather moves KiBs instead of GiBs.
+ * In two-sided mode bins k and N-k carry identical values here, so the peak is the lower
+ * index k (the reference picks whichever f64 rounding favours). */
+PDSP_API int pdsp_spectrum_peaks_f32(const pdsp_plan *plan, long long batch,
+                                     const float *frames, long long frame_len, long long frame_stride,
+                                     const float *window, int sides, double sample_rate,
+                                     float *amp_out, float *phase_out, pdsp_peak32 *peaks_out,
+                                     pdsp_stream stream);
 
 /* ---- host f64 drop-in entry points (synchronous) ----------------------- */
 

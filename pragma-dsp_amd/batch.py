@@ -132,6 +132,37 @@ class BatchedFft:
         return amp, ph, pk
 
 
+    def spectrum_peaks(self, frames: torch.Tensor, window="rect", sides: str = "one", sample_rate: float = 1.0,
+                       want_amp: bool = False, want_phase: bool = False):
+        """Rows of the whole spectrum() tail on the device: one SpectrumPeak per frame
+        (findPeak fused into the kernel).  Returns (index int32 [...], frequency, amplitude,
+        phase float32 [...], amp-or-None, phase-or-None); with want_amp=False only 16 bytes
+        per frame leave the kernel."""
+        if frames.dtype != torch.float32 or not frames.is_cuda or not frames.is_contiguous():
+            raise PdspError(_capi.ERR_BAD_ARG, "frames must be a contiguous float32 CUDA tensor")
+        if sample_rate <= 0:
+            raise PdspError(_capi.ERR_SAMPLE_RATE, f"Sample rate must be positive, got {js_num(sample_rate)}")
+        length = frames.shape[-1]
+        batch = frames.numel() // length if length else 0
+        two = sides != "one"
+        bins = self.size if two else self.size // 2 + 1
+        if isinstance(window, str):
+            if self.size != 1 and window not in _capi.WINDOW_TYPES:
+                raise PdspError(_capi.ERR_WINDOW_TYPE, f"Unsupported window type: {window}")
+            win = None if (window == "rect" or self.size == 1) else self.window(window)
+        else:
+            win = window
+        shape = tuple(frames.shape[:-1])
+        amp = torch.empty(shape + (bins,), dtype=torch.float32, device=self.device) if (want_amp or want_phase) else None
+        ph = torch.empty(shape + (bins,), dtype=torch.float32, device=self.device) if want_phase else None
+        rec = torch.empty(shape + (4,), dtype=torch.int32, device=self.device)  # pdsp_peak32 records
+        check(lib.pdsp_spectrum_peaks_f32(self._h, batch, _ptr(frames), min(length, self.size), length, _ptr(win),
+                                          1 if two else 0, float(sample_rate), _ptr(amp), _ptr(ph), _ptr(rec),
+                                          _stream_ptr(self.device)))
+        f = rec.view(torch.float32)
+        return rec[..., 0], f[..., 1], f[..., 2], f[..., 3], amp, ph
+
+
 # -- stand-alone element-wise device helpers ----------------------------------
 
 def apply_window(frames: torch.Tensor, window: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

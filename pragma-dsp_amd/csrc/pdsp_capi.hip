@@ -132,19 +132,26 @@ hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, l
 }
 
 template <int LOG2M>
-hipError_t launch_packed_one(bool fast, const float *frames, const float *win, long long frame_len,
-                             long long stride, const float2 *tw, const float2 *twr, float *amp, float *ph,
-                             int two_sided, float s_edge, float s_mid, long long batch, hipStream_t s) {
+hipError_t launch_packed_one(bool fast, const float *frames, const float *win, long long frame_len, long long stride,
+                             const float2 *tw, const float2 *twr, float *amp, float *ph, int two_sided, float s_edge,
+                             float s_mid, pdsp::PeakRec *peaks, float freq_scale, long long batch, hipStream_t s) {
   using TR = pdsp::FftTraits<LOG2M>;
   const long long ngroups = (batch + TR::ROWS - 1) / TR::ROWS;
   const dim3 block(TR::WG);
-#define PDSP_LAUNCH(F, W)                                                                                       \
-  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, LOG2M, F, W>), dim3((unsigned)ngroups), block, 0, s, \
-                     frames, win, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, batch)
-  if (fast && win) PDSP_LAUNCH(true, true);
-  else if (fast) PDSP_LAUNCH(true, false);
-  else if (win) PDSP_LAUNCH(false, true);
-  else PDSP_LAUNCH(false, false);
+#define PDSP_LAUNCH(F, W, P)                                                                                      \
+  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, LOG2M, F, W, P>), dim3((unsigned)ngroups), block, 0, s, \
+                     frames, win, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, peaks, freq_scale, \
+                     batch)
+#define PDSP_LAUNCH_FW(F, W)     \
+  do {                           \
+    if (peaks) PDSP_LAUNCH(F, W, true); \
+    else PDSP_LAUNCH(F, W, false);      \
+  } while (0)
+  if (fast && win) PDSP_LAUNCH_FW(true, true);
+  else if (fast) PDSP_LAUNCH_FW(true, false);
+  else if (win) PDSP_LAUNCH_FW(false, true);
+  else PDSP_LAUNCH_FW(false, false);
+#undef PDSP_LAUNCH_FW
 #undef PDSP_LAUNCH
   return hipGetLastError();
 }
@@ -523,52 +530,86 @@ int pdsp_phase_f32(long long count, const float *re, const float *im, float *out
 
 /* ---- fused spectrum ---------------------------------------------------------- */
 
-int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
-                      long long frame_stride, const float *window, int sides, float *amp_out, float *phase_out,
-                      int32_t *peak_out, pdsp_stream stream) {
+static int spectrum_impl(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
+                         long long frame_stride, const float *window, int sides, float *amp_out, float *phase_out,
+                         int32_t *peak_idx_out, pdsp_peak32 *peaks_out, double sample_rate, hipStream_t stream) {
   if (int rc = check_plan_batch(plan, batch)) return rc;
   if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
   if (frame_len < 0 || frame_stride < frame_len) return fail(PDSP_ERR_BAD_ARG, "bad frame_len/frame_stride");
+  if (peaks_out && sample_rate <= 0)
+    return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
   if (batch == 0) return PDSP_OK;
-  if (!frames || !amp_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  if (!frames || (!amp_out && !peaks_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  if ((phase_out || peak_idx_out) && !amp_out) return fail(PDSP_ERR_BAD_ARG, "phase/peak index output needs amp_out");
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
+  static_assert(sizeof(pdsp_peak32) == sizeof(pdsp::PeakRec), "peak record layout");
   const long long n = plan->n;
   const int bins = (int)(sides == PDSP_SIDES_ONE ? n / 2 + 1 : n);
   const long long used = frame_len < n ? frame_len : n;
+  const float freq_scale = peaks_out ? (float)(sample_rate / (double)n) : 0.0f;
   if (used == 0) {  // an empty frame is all zeros: amplitude 0, atan2(0, 0) = 0, peak 0
-    PDSP_HIP_TRY(hipMemsetAsync(amp_out, 0, (size_t)batch * bins * sizeof(float), (hipStream_t)stream));
-    if (phase_out) PDSP_HIP_TRY(hipMemsetAsync(phase_out, 0, (size_t)batch * bins * sizeof(float), (hipStream_t)stream));
-    if (peak_out) PDSP_HIP_TRY(hipMemsetAsync(peak_out, 0, (size_t)batch * sizeof(int32_t), (hipStream_t)stream));
+    if (amp_out) PDSP_HIP_TRY(hipMemsetAsync(amp_out, 0, (size_t)batch * bins * sizeof(float), stream));
+    if (phase_out) PDSP_HIP_TRY(hipMemsetAsync(phase_out, 0, (size_t)batch * bins * sizeof(float), stream));
+    if (peak_idx_out) PDSP_HIP_TRY(hipMemsetAsync(peak_idx_out, 0, (size_t)batch * sizeof(int32_t), stream));
+    if (peaks_out) PDSP_HIP_TRY(hipMemsetAsync(peaks_out, 0, (size_t)batch * sizeof(pdsp_peak32), stream));
     return PDSP_OK;
   }
   const float s_edge = 1.0f / (float)n, s_mid = (sides == PDSP_SIDES_ONE ? 2.0f : 1.0f) / (float)n;
   if (plan->d_tw32_half && (window == nullptr || ((uintptr_t)window & 7) == 0)) {
-    // packed-real path: N/2-point complex transform + Hermitian split fused with the store
-    // fast variant: whole 8-byte aligned frames, one-sided amplitude only (config 4's shape)
+    // packed-real path: N/2-point complex transform + Hermitian split (+ findPeak) fused with the store.
+    // fast variant: whole 8-byte aligned frames, one-sided, no phase rows (config 4's shape)
     const bool fast = ((uintptr_t)frames & 7) == 0 && (frame_stride & 1) == 0 && used == n &&
                       sides == PDSP_SIDES_ONE && phase_out == nullptr;
     PDSP_HIP_TRY(launch_packed(plan->log2n - 1, fast, frames, window, used, frame_stride, plan->d_tw32_half,
-                               plan->d_twr32, amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid, batch,
-                               (hipStream_t)stream));
+                               plan->d_twr32, amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
+                               reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
   } else {
-    pdsp::StoreAmplitude<float> st{amp_out, phase_out, bins,
+    // complex kernel on (x, 0) for N < 64 or an unaligned window; peaks come from the stored rows
+    float *amp = amp_out, *ph = phase_out;
+    const size_t row_bytes = (size_t)batch * bins * sizeof(float);
+    if (peaks_out && !amp) PDSP_HIP_TRY(hipMallocAsync((void **)&amp, row_bytes, stream));
+    if (peaks_out && !ph) PDSP_HIP_TRY(hipMallocAsync((void **)&ph, row_bytes, stream));
+    pdsp::StoreAmplitude<float> st{amp, ph, bins,
                                    // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
                                    (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1, s_edge, s_mid};
     if (window) {
       pdsp::LoadFrameWindowed<float, true> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, (hipStream_t)stream));
+      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, stream));
     } else {
       pdsp::LoadFrameWindowed<float, false> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, (hipStream_t)stream));
+      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, stream));
+    }
+    if (peaks_out) {
+      hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<float>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph,
+                         bins, freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
+      PDSP_HIP_TRY(hipGetLastError());
+      if (!amp_out) PDSP_HIP_TRY(hipFreeAsync(amp, stream));
+      if (!phase_out) PDSP_HIP_TRY(hipFreeAsync(ph, stream));
     }
   }
-  if (peak_out) {
-    hipLaunchKernelGGL((pdsp::find_peak_kernel<float>), dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream,
-                       amp_out, bins, peak_out, batch);
+  if (peak_idx_out) {
+    hipLaunchKernelGGL((pdsp::find_peak_kernel<float>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
+                       peak_idx_out, batch);
     PDSP_HIP_TRY(hipGetLastError());
   }
   return PDSP_OK;
+}
+
+int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
+                      long long frame_stride, const float *window, int sides, float *amp_out, float *phase_out,
+                      int32_t *peak_out, pdsp_stream stream) {
+  if (batch > 0 && !amp_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  return spectrum_impl(plan, batch, frames, frame_len, frame_stride, window, sides, amp_out, phase_out, peak_out,
+                       nullptr, 1.0, (hipStream_t)stream);
+}
+
+int pdsp_spectrum_peaks_f32(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
+                            long long frame_stride, const float *window, int sides, double sample_rate,
+                            float *amp_out, float *phase_out, pdsp_peak32 *peaks_out, pdsp_stream stream) {
+  if (batch > 0 && !peaks_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  return spectrum_impl(plan, batch, frames, frame_len, frame_stride, window, sides, amp_out, phase_out, nullptr,
+                       peaks_out, sample_rate, (hipStream_t)stream);
 }
 
 /* ---- host f64 drop-in entry points ------------------------------------------ */

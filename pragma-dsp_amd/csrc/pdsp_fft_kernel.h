@@ -318,6 +318,32 @@ __device__ __forceinline__ void fft_passes(cx<T> (&x)[FftTraits<LOG2N>::E], cx<T
   });
 }
 
+// ---- findPeak on the device ------------------------------------------------------
+// SpectrumPeak per frame (src/public/spectrum.ts:15-20) in f32; layout == pdsp_peak32.
+struct PeakRec {
+  int index;
+  float frequency;
+  float amplitude;
+  float phase;
+};
+
+// Running arg-max with findPeak's rules (spectrum.ts:74-105) over bins >= 1: a larger
+// value wins; an equal value wins only with a smaller index ("strict >, first wins",
+// made order-independent); only values > 0 ever enter (index 0 = "no bin > 0 yet").
+template <typename T>
+struct PeakBest {
+  T v;
+  int i;
+  cx<T> x;  // the complex bin, so the phase is one atan2 at the very end
+  __device__ __forceinline__ void consider(const T ov, const int oi, const cx<T> ox) {
+    if (ov > v || (ov == v && ov > T(0) && oi < i)) {
+      v = ov;
+      i = oi;
+      x = ox;
+    }
+  }
+};
+
 // ---- the kernels ---------------------------------------------------------------
 
 template <typename T, int LOG2N, class LD, class ST>
@@ -360,13 +386,15 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
 //         mirror code stays out of the (VALU-issue bound) instruction stream.
 //   !FAST: any frame_len >= 1 / alignment (scalar clamped loads + selects), phase and
 //         two-sided output at run time.
-template <typename T, int LOG2M, bool FAST, bool HAS_WIN>
+//   PEAK: also reduce each frame to its SpectrumPeak (findPeak fused; `amp` may then be
+//         null = peaks-only output, 16 B per frame instead of 2*(N/2+1) B).
+template <typename T, int LOG2M, bool FAST, bool HAS_WIN, bool PEAK>
 __global__ void __launch_bounds__(FftTraits<LOG2M>::WG)
 spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, const long long frame_len,
                        const long long stride, const typename vec2<T>::type *__restrict__ tw,
                        const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp,
                        T *__restrict__ ph, const int two_sided, const T s_edge, const T s_mid,
-                       const long long batch) {
+                       PeakRec *__restrict__ peaks, const T freq_scale, const long long batch) {
   using TR = FftTraits<LOG2M>;
   constexpr int E = TR::E, TP = TR::TP, M = TR::N;
   static_assert(LOG2M >= 5, "packed path needs TP >= 2");
@@ -404,11 +432,14 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   fft_passes<T, LOG2M, true>(x, lrow, reinterpret_cast<const cx<T> *>(tw), tid);
   __syncthreads();
 
-  if (!live) return;
   const int bins = (!FAST && two_sided) ? 2 * M : M + 1;
+  const bool store_amp = live && (!PEAK || amp != nullptr);
   T *const arow = amp + (size_t)row * (size_t)bins;
   T *const prow = (!FAST && ph) ? ph + (size_t)row * (size_t)bins : nullptr;
   const cx<T> *const twk = reinterpret_cast<const cx<T> *>(twr);
+  PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
+  T dc_amp = T(0);
+  cx<T> dc_x{T(0), T(0)};
   // pairs k = tid + TP*q, q < E/2 (k < M/2); k = M/2 is one more pair for tid == 0.
   // LDS: Z[k] at pad(tid) + q*cpad(TP); Z[M-k] at pad(M - tid) - q*cpad(TP); Z[M] == Z[0].
   const cx<T> *const zlo = lrow + lds_pad(tid);
@@ -435,24 +466,80 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       // bins 0 (DC, from k = 0) and M (Nyquist, the partner of k = 0) are not doubled
       const T sc = (k == 0) ? s_edge : s_mid;
       const T ma = mag(xa) * sc, mb = mag(xb) * sc;
-      st_rowtail(ma, arow + (unsigned)k);
-      if (k2 != k) st_rowtail(mb, arow + (unsigned)k2);
-      if constexpr (!FAST) {
-        if (two_sided && k != 0) {  // X[N-k] = conj X[k]
-          st_rowtail(ma, arow + (unsigned)(2 * M - k));
-          if (k2 != k) st_rowtail(mb, arow + (unsigned)(2 * M - k2));
+      if constexpr (PEAK) {
+        // the mirrored two-sided bins N-k carry identical values at larger indices, so
+        // the strict-'>' search never selects them: bins 1..M decide
+        if (k == 0) {
+          dc_amp = ma;
+          dc_x = xa;
+        } else {
+          best.consider(ma, k, xa);
         }
-        if (prow) {
-          st_rowtail(T(atan2(xa.y, xa.x)), prow + (unsigned)k);
-          if (k2 != k) st_rowtail(T(atan2(xb.y, xb.x)), prow + (unsigned)k2);
-          if (two_sided && k != 0) {
-            st_rowtail(T(atan2(-xa.y, xa.x)), prow + (unsigned)(2 * M - k));
-            if (k2 != k) st_rowtail(T(atan2(-xb.y, xb.x)), prow + (unsigned)(2 * M - k2));
+        if (k2 != k) best.consider(mb, k2, xb);
+      }
+      if (store_amp) {
+        st_rowtail(ma, arow + (unsigned)k);
+        if (k2 != k) st_rowtail(mb, arow + (unsigned)k2);
+        if constexpr (!FAST) {
+          if (two_sided && k != 0) {  // X[N-k] = conj X[k]
+            st_rowtail(ma, arow + (unsigned)(2 * M - k));
+            if (k2 != k) st_rowtail(mb, arow + (unsigned)(2 * M - k2));
+          }
+          if (prow) {
+            st_rowtail(T(atan2(xa.y, xa.x)), prow + (unsigned)k);
+            if (k2 != k) st_rowtail(T(atan2(xb.y, xb.x)), prow + (unsigned)k2);
+            if (two_sided && k != 0) {
+              st_rowtail(T(atan2(-xa.y, xa.x)), prow + (unsigned)(2 * M - k));
+              if (k2 != k) st_rowtail(T(atan2(-xb.y, xb.x)), prow + (unsigned)(2 * M - k2));
+            }
           }
         }
       }
     }
   });
+
+  if constexpr (PEAK) {
+    // row-wide arg-max: butterflies inside the wave, then one LDS hop across the row's waves
+    constexpr int WSPAN = TP < 64 ? TP : 64;
+    static_for<ilog2(WSPAN)>([&](auto sc) {
+      constexpr int off = WSPAN >> (sc + 1);
+      PeakBest<T> o;
+      o.v = __shfl_xor(best.v, off, 64);
+      o.i = __shfl_xor(best.i, off, 64);
+      o.x = cx<T>{__shfl_xor(best.x.x, off, 64), __shfl_xor(best.x.y, off, 64)};
+      best.consider(o.v, o.i, o.x);
+    });
+    if constexpr (TP > 64) {
+      constexpr int WAVES = TP / 64;  // waves per row; ROWS == 1 or WG/TP rows of WAVES waves
+      __shared__ T pk_v[TR::WG / 64];
+      __shared__ int pk_i[TR::WG / 64];
+      __shared__ cx<T> pk_x[TR::WG / 64];
+      const int wave = (int)threadIdx.x / 64;
+      if ((threadIdx.x & 63) == 0) {
+        pk_v[wave] = best.v;
+        pk_i[wave] = best.i;
+        pk_x[wave] = best.x;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        static_for<WAVES - 1>([&](auto wc) {
+          const int w = rloc * WAVES + wc + 1;
+          best.consider(pk_v[w], pk_i[w], pk_x[w]);
+        });
+      }
+    }
+    if (live && tid == 0) {
+      // nothing > 0 beyond DC: findPeak falls back to the global max, which is bin 0
+      const bool none = best.i == 0;
+      const cx<T> px = none ? dc_x : best.x;
+      PeakRec r;
+      r.index = best.i;
+      r.frequency = (float)(T(best.i) * freq_scale);
+      r.amplitude = (float)(none ? dc_amp : best.v);
+      r.phase = (float)atan2(px.y, px.x);
+      peaks[row] = r;
+    }
+  }
 }
 
 // ---- element-wise kernels (stand-alone applyWindow / magnitude / phase) -----
@@ -473,6 +560,51 @@ polar_kernel(const T *__restrict__ re, const T *__restrict__ im, T *__restrict__
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
     const T a = re[i], b = im[i];
     out[i] = PHASE ? T(atan2(b, a)) : T(sqrt(a * a + b * b));
+  }
+}
+
+// SpectrumPeak per frame from stored amplitude (and phase) rows: the fallback of the fused
+// PEAK path for sizes / alignments the packed kernel does not take.  One workgroup per row.
+template <typename T>
+__global__ void __launch_bounds__(256)
+peak_from_rows_kernel(const T *__restrict__ amp, const T *__restrict__ ph, int bins, T freq_scale,
+                      PeakRec *__restrict__ peaks, long long batch) {
+  __shared__ T sv[256];
+  __shared__ int si[256];
+  const long long row = blockIdx.x;
+  if (row >= batch) return;
+  const T *a = amp + (size_t)row * (size_t)bins;
+  T bv = T(0);
+  int bi = 0;
+  for (int i = 1 + (int)threadIdx.x; i < bins; i += 256) {
+    const T v = a[i];
+    if (v > bv) {
+      bv = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const T ov = sv[threadIdx.x + s], mv = sv[threadIdx.x];
+      const int oi = si[threadIdx.x + s], mi = si[threadIdx.x];
+      if (ov > mv || (ov == mv && ov > T(0) && oi < mi)) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int idx = si[0];
+    PeakRec r;
+    r.index = idx;
+    r.frequency = (float)(T(idx) * freq_scale);
+    r.amplitude = (float)a[idx];
+    r.phase = ph ? (float)ph[(size_t)row * (size_t)bins + idx] : 0.0f;
+    peaks[row] = r;
   }
 }
 
