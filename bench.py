@@ -155,7 +155,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "spectrum16k", "single1024"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "spectrum16k", "peaks16k", "single1024"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,7 +183,7 @@ def main() -> int:
     if args.workload == "single1024":
         return single_frame_latency(args, dev)
 
-    if args.workload == "spectrum16k":
+    if args.workload in ("spectrum16k", "peaks16k"):
         n, per_gpu = 16384, args.batch or (1 << 20)
     else:
         n, per_gpu = 4096, args.batch or 65536
@@ -199,7 +199,7 @@ def main() -> int:
         ore, oim = torch.empty_like(re), torch.empty_like(im)
         launches_per_step = 1
         bytes_per_launch = 16 * per_gpu * n  # 8 B read + 8 B written per sample
-        kernel_name = "LoadComplex"
+        kernel_name, kernel_label = "LoadComplex", "fft_stockham_kernel<float, 12, LoadComplex, StoreComplex>"
 
         def step():
             plan.forward(re, im, out=(ore, oim))
@@ -209,10 +209,23 @@ def main() -> int:
         ore, oim = torch.empty_like(re), torch.empty_like(re)
         launches_per_step = 1
         bytes_per_launch = 12 * per_gpu * n
-        kernel_name = "LoadReal"
+        kernel_name, kernel_label = "LoadReal", "fft_stockham_kernel<float, 12, LoadReal, StoreComplex>"
 
         def step():
             plan.forward(re, None, out=(ore, oim))
+    elif args.workload == "peaks16k":
+        chunk = min(args.chunk, per_gpu)
+        assert per_gpu % chunk == 0
+        re, _ = synth_batch(chunk, n, dev, seed=1337 + rank, complex_noise=False)
+        im = None
+        launches_per_step = per_gpu // chunk
+        bytes_per_launch = (4 * n + 16) * chunk  # frame in, one 16-byte SpectrumPeak out
+        kernel_name = kernel_label = "spectrum_packed_kernel<float, 13, true, true, true>"
+        plan.window("hann")
+
+        def step():
+            for _ in range(launches_per_step):
+                plan.spectrum_peaks(re, "hann", "one", 48000.0)
     else:
         chunk = min(args.chunk, per_gpu)
         assert per_gpu % chunk == 0
@@ -222,7 +235,7 @@ def main() -> int:
         amp = torch.empty((chunk, bins), dtype=torch.float32, device=dev)
         launches_per_step = per_gpu // chunk
         bytes_per_launch = (4 * n + 4 * bins) * chunk  # 98,308 B per frame
-        kernel_name = "LoadFrameWindowed"
+        kernel_name = kernel_label = "spectrum_packed_kernel<float, 13, true, true, false>"
         plan.window("hann")
 
         def step():
@@ -261,7 +274,7 @@ def main() -> int:
     elapsed = max_over_ranks(elapsed, dev)
 
     gather = None
-    if args.gather and world > 1 and args.workload != "spectrum16k":
+    if args.gather and world > 1 and args.workload in ("fft4096", "real4096"):
         # the one exchange step of the path: RCCL all-gather of the output slabs,
         # timed on its own -- at 2 GiB/rank it is xGMI-per-link bound and dwarfs the compute
         gather_rows(ore, per_gpu * world)  # warm-up (communicator setup)
@@ -298,12 +311,13 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": {"fft4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex (configs[2])",
                                     "real4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forward fp32 real input",
-                                    "spectrum16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude (configs[3])"}[args.workload],
+                                    "spectrum16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude (configs[3])",
+                                    "peaks16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+findPeak, peaks-only output"}[args.workload],
                        "n": n, "batch_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "parallelism": f"batch-shard x{world}", "launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profile(kernel_name),
-                         "kernel": f"fft_stockham_kernel<float,{int(np.log2(n))},{kernel_name}...>",
+                         "kernel": kernel_label,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launch_ms_avg": launch_ms, "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
         }
@@ -312,7 +326,7 @@ def main() -> int:
         if world == 1 and not args.no_cpu_baseline:
             rows = 2048
             sel = torch.cat([torch.arange(0, rows // 2), torch.arange(per_gpu // 2, per_gpu // 2 + rows // 2)]) \
-                if args.workload != "spectrum16k" else torch.arange(0, min(rows, re.shape[0]))
+                if args.workload in ("fft4096", "real4096") else torch.arange(0, min(rows, re.shape[0]))
             hre = re[sel.to(dev)].cpu().numpy().astype(np.float64)
             him = im[sel.to(dev)].cpu().numpy().astype(np.float64) if im is not None else None
             out["cpu_baseline"] = cpu_baseline(hre, him, n, args.cpu_seconds)

@@ -154,6 +154,22 @@ PDSP_API int pdsp_magnitude_f32(long long count, const float *re, const float *i
 PDSP_API int pdsp_phase_f32(long long count, const float *re, const float *im,
                             float *out, pdsp_stream stream);
 
+/* Element-wise complex vector arithmetic on planar device rows, src/math/complex.ts:26-197
+ * (scaleInto, addInto, subInto, mulInto, mulScalarInto, divInto, conjInto), so FFT-domain
+ * pipelines (forward -> mul -> inverse, test/fluent/chain.test.ts:287-317) stay in HBM.
+ * out = a OP b for the binary ops, where b holds b_len values and is broadcast over the
+ * count/b_len rows of a when b_len < count (b_len must divide count); out = a OP (s_re, s_im)
+ * for SCALE (real s_re) and MUL_SCALAR; out = conj(a) for CONJ.  divScalar is MUL_SCALAR by the
+ * host-computed reciprocal, as complex.ts:176-186 does.  out may alias a. */
+typedef enum pdsp_complex_op {
+  PDSP_CX_ADD = 0, PDSP_CX_SUB = 1, PDSP_CX_MUL = 2, PDSP_CX_DIV = 3,
+  PDSP_CX_CONJ = 4, PDSP_CX_SCALE = 5, PDSP_CX_MUL_SCALAR = 6
+} pdsp_complex_op;
+PDSP_API int pdsp_complex_op_f32(int op, long long count, const float *a_re, const float *a_im,
+                                 const float *b_re, const float *b_im, long long b_len,
+                                 double s_re, double s_im, float *out_re, float *out_im,
+                                 pdsp_stream stream);
+
 /* ---- fused spectrum (f32) ---------------------------------------------- */
 
 /* The batched body of spectrum(), src/public/spectrum.ts:116-131, one frame per

@@ -10,6 +10,7 @@ from .oracle import (  # noqa: F401
     apply_window,
     bin_frequencies,
     build,
+    complex_op,
     create_window,
     fft_shift,
     find_peak,

@@ -57,6 +57,8 @@ def _L():
                                         dp, dp, dp, C.POINTER(_Peak)]
         lib.oracle_spectrum_batch.argtypes = [C.c_void_p, C.c_longlong, dp, dp, C.c_int, dp, dp,
                                               C.POINTER(C.c_int)]
+        lib.oracle_complex_op.argtypes = [C.c_int, C.c_longlong, dp, dp, dp, dp, C.c_longlong, C.c_double,
+                                          C.c_double, dp, dp]
         lib.oracle_time_forward.argtypes = [C.c_void_p, C.c_longlong, C.c_int, dp, dp, dp]
         lib.oracle_time_forward.restype = C.c_double
         _lib = lib
@@ -226,3 +228,17 @@ def spectrum(samples, sample_rate=1.0, fft_size=None, window="rect", sides="one"
         "peak": {"index": pk.index, "frequency": pk.frequency,
                  "amplitude": pk.amplitude, "phase": pk.phase},
     }
+
+
+COMPLEX_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "conj": 4, "scale": 5, "mulScalar": 6}
+
+
+def complex_op(name, are, aim, bre=None, bim=None, s_re=0.0, s_im=0.0):
+    """src/math/complex.ts restated; b broadcasts over the rows of a."""
+    are, aim = _f64(are), _f64(aim)
+    bre = _f64(bre) if bre is not None else None
+    bim = _f64(bim) if bim is not None else None
+    orr, oi = np.empty_like(are), np.empty_like(are)
+    _L().oracle_complex_op(COMPLEX_OPS[name], are.size, _p(are), _p(aim), _p(bre), _p(bim),
+                           bre.size if bre is not None else 1, float(s_re), float(s_im), _p(orr), _p(oi))
+    return orr, oi

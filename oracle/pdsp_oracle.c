@@ -313,6 +313,28 @@ ORACLE_API void oracle_spectrum_batch(const oracle_plan *p, long long batch,
   free(buf);
 }
 
+/* ---------------------------------------------------------- complex vectors */
+
+/* src/math/complex.ts:26-197 -- op: 0 add, 1 sub, 2 mul, 3 div, 4 conj, 5 scale(s_re),
+ * 6 mulScalar(s_re, s_im).  b is broadcast with period b_len (the device API's row
+ * broadcast; b_len == n is the reference's element-wise case). */
+ORACLE_API void oracle_complex_op(int op, long long n, const double *ar, const double *ai, const double *br,
+                                  const double *bi, long long b_len, double s_re, double s_im, double *orr,
+                                  double *oi) {
+  for (long long i = 0; i < n; ++i) {
+    const double a = ar[i], b = ai[i];
+    const double c = op <= 3 ? br[i % b_len] : s_re, d = op <= 3 ? bi[i % b_len] : s_im;
+    switch (op) {
+      case 0: orr[i] = a + c; oi[i] = b + d; break;
+      case 1: orr[i] = a - c; oi[i] = b - d; break;
+      case 2: case 6: orr[i] = a * c - b * d; oi[i] = a * d + b * c; break;
+      case 3: { const double den = c * c + d * d; orr[i] = (a * c + b * d) / den; oi[i] = (b * c - a * d) / den; break; }
+      case 4: orr[i] = a; oi[i] = -b; break;
+      default: orr[i] = a * c; oi[i] = b * c; break;
+    }
+  }
+}
+
 /* ------------------------------------------------------- cpu_baseline leg */
 
 /* Times `reps` passes of the reference's caller loop (plan and `out` reused,

@@ -27,6 +27,7 @@ ERR_DEVICE = 10
 
 WINDOW_TYPES = {"rect": 0, "hann": 1, "hamming": 2, "blackman": 3}
 SIDES = {"one": 0, "two": 1}
+COMPLEX_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "conj": 4, "scale": 5, "mulScalar": 6}
 
 
 class PdspError(Exception):
@@ -72,6 +73,7 @@ def _load() -> C.CDLL:
         "pdsp_apply_window_f32": ([ll, ll, vp, vp, vp, vp], i32),
         "pdsp_magnitude_f32": ([ll, vp, vp, vp, vp], i32),
         "pdsp_phase_f32": ([ll, vp, vp, vp, vp], i32),
+        "pdsp_complex_op_f32": ([i32, ll, vp, vp, vp, vp, ll, dbl, dbl, vp, vp, vp], i32),
         "pdsp_spectrum_f32": ([vp, ll, vp, ll, ll, vp, i32, vp, vp, vp, vp], i32),
         "pdsp_spectrum_peaks_f32": ([vp, ll, vp, ll, ll, vp, i32, dbl, vp, vp, vp, vp], i32),
         "pdsp_fft_transform_host_f64": ([vp, ll, ll, dp, dp, dp, dp, i32], i32),

@@ -185,3 +185,55 @@ def phase(re: torch.Tensor, im: torch.Tensor, out: torch.Tensor | None = None) -
     out = torch.empty_like(re) if out is None else out
     check(lib.pdsp_phase_f32(re.numel(), _ptr(re), _ptr(im), _ptr(out), _stream_ptr(re.device)))
     return out
+
+
+# -- element-wise complex vector arithmetic (src/math/complex.ts) on device rows ------
+
+def _complex_op(name, a, b=None, s_re=0.0, s_im=0.0, out=None):
+    are, aim = a
+    ore, oim = (torch.empty_like(are), torch.empty_like(aim)) if out is None else out
+    bre = bim = None
+    b_len = 0
+    if b is not None:
+        bre, bim = b
+        b_len = bre.numel()
+        if are.numel() % max(b_len, 1) != 0:
+            raise PdspError(_capi.ERR_BAD_ARG, f"second operand length {b_len} must divide {are.numel()}")
+    check(lib.pdsp_complex_op_f32(_capi.COMPLEX_OPS[name], are.numel(), _ptr(are), _ptr(aim), _ptr(bre), _ptr(bim),
+                                  b_len, float(s_re), float(s_im), _ptr(ore), _ptr(oim), _stream_ptr(are.device)))
+    return ore, oim
+
+
+def complex_add(a, b, out=None):
+    return _complex_op("add", a, b, out=out)
+
+
+def complex_sub(a, b, out=None):
+    return _complex_op("sub", a, b, out=out)
+
+
+def complex_mul(a, b, out=None):
+    """Hadamard product; `b` may be one row broadcast over the rows of `a`."""
+    return _complex_op("mul", a, b, out=out)
+
+
+def complex_div(a, b, out=None):
+    return _complex_op("div", a, b, out=out)
+
+
+def complex_conj(a, out=None):
+    return _complex_op("conj", a, out=out)
+
+
+def complex_scale(a, s, out=None):
+    return _complex_op("scale", a, s_re=s, out=out)
+
+
+def complex_mul_scalar(a, re, im, out=None):
+    return _complex_op("mulScalar", a, s_re=re, s_im=im, out=out)
+
+
+def complex_div_scalar(a, re, im, out=None):
+    """complex.ts:176-186: multiply by the reciprocal computed on the host."""
+    denom = re * re + im * im
+    return _complex_op("mulScalar", a, s_re=re / denom, s_im=-im / denom, out=out)

@@ -296,6 +296,23 @@ int require_device() {
   return PDSP_OK;
 }
 
+template <int OP>
+int launch_complex_op(long long count, const float *are, const float *aim, const float *bre, const float *bim,
+                      long long b_len, float sre, float sim, float *ore, float *oim, hipStream_t s) {
+  const bool binary = OP <= pdsp::kDiv;
+  const uintptr_t align = (uintptr_t)are | (uintptr_t)aim | (uintptr_t)ore | (uintptr_t)oim |
+                          (binary ? ((uintptr_t)bre | (uintptr_t)bim) : 0);
+  const bool vec4 = (align & 15) == 0 && count % 4 == 0 && (!binary || b_len % 4 == 0);
+  if (vec4)
+    hipLaunchKernelGGL((pdsp::complex_op_kernel<float, OP, 4>), dim3(grid_for(count / 4)), dim3(256), 0, s, are, aim,
+                       bre, bim, sre, sim, ore, oim, count, b_len);
+  else
+    hipLaunchKernelGGL((pdsp::complex_op_kernel<float, OP, 1>), dim3(grid_for(count)), dim3(256), 0, s, are, aim, bre,
+                       bim, sre, sim, ore, oim, count, b_len);
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -526,6 +543,32 @@ int pdsp_phase_f32(long long count, const float *re, const float *im, float *out
                      re, im, out, count);
   PDSP_HIP_TRY(hipGetLastError());
   return PDSP_OK;
+}
+
+int pdsp_complex_op_f32(int op, long long count, const float *a_re, const float *a_im, const float *b_re,
+                        const float *b_im, long long b_len, double s_re, double s_im, float *out_re, float *out_im,
+                        pdsp_stream stream) {
+  if (count < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
+  if (op < PDSP_CX_ADD || op > PDSP_CX_MUL_SCALAR) return fail(PDSP_ERR_BAD_ARG, "unknown complex op %d", op);
+  if (count == 0) return PDSP_OK;
+  if (!a_re || !a_im || !out_re || !out_im) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  const bool binary = op <= PDSP_CX_DIV;
+  if (binary) {
+    if (!b_re || !b_im) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+    if (b_len <= 0 || count % b_len != 0)
+      return fail(PDSP_ERR_BAD_ARG, "second operand length %lld must divide %lld", b_len, count);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const float sr = (float)s_re, si = (float)s_im;
+  switch (op) {
+    case PDSP_CX_ADD: return launch_complex_op<pdsp::kAdd>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
+    case PDSP_CX_SUB: return launch_complex_op<pdsp::kSub>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
+    case PDSP_CX_MUL: return launch_complex_op<pdsp::kMul>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
+    case PDSP_CX_DIV: return launch_complex_op<pdsp::kDiv>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
+    case PDSP_CX_CONJ: return launch_complex_op<pdsp::kConj>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
+    case PDSP_CX_SCALE: return launch_complex_op<pdsp::kScale>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
+    default: return launch_complex_op<pdsp::kMulScalar>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
+  }
 }
 
 /* ---- fused spectrum ---------------------------------------------------------- */

@@ -563,6 +563,81 @@ polar_kernel(const T *__restrict__ re, const T *__restrict__ im, T *__restrict__
   }
 }
 
+// Batched element-wise complex arithmetic on planar rows (src/math/complex.ts:26-197:
+// add, sub, mul, div, conj, scale, mulScalar), so forward -> mul -> inverse pipelines
+// (FFT-domain convolution, test/fluent/chain.test.ts:287-317) stay in HBM.  The second
+// operand may be one row of `b_len` values broadcast over the batch (a filter response).
+enum ComplexOp { kAdd = 0, kSub = 1, kMul = 2, kDiv = 3, kConj = 4, kScale = 5, kMulScalar = 6 };
+
+template <typename T, int OP>
+__device__ __forceinline__ void complex_op1(T ar, T ai, T br, T bi, T &orr, T &oi) {
+  if constexpr (OP == kAdd) {
+    orr = ar + br;
+    oi = ai + bi;
+  } else if constexpr (OP == kSub) {
+    orr = ar - br;
+    oi = ai - bi;
+  } else if constexpr (OP == kMul || OP == kMulScalar) {  // (ac - bd) + i(ad + bc)
+    orr = ar * br - ai * bi;
+    oi = ar * bi + ai * br;
+  } else if constexpr (OP == kDiv) {  // ((ac + bd) + i(bc - ad)) / (c^2 + d^2), complex.ts:150-161
+    const T denom = br * br + bi * bi;
+    orr = (ar * br + ai * bi) / denom;
+    oi = (ai * br - ar * bi) / denom;
+  } else if constexpr (OP == kConj) {
+    orr = ar;
+    oi = -ai;
+  } else {  // kScale: real scalar in br
+    orr = ar * br;
+    oi = ai * br;
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void ld_vec(const T *p, long long i, T (&v)[V]) {
+  if constexpr (V == 4) {
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    const V4 t = reinterpret_cast<const V4 *>(p)[i];
+    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+  } else {
+    v[0] = p[i];
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ void st_vec(T *p, long long i, const T (&v)[V]) {
+  if constexpr (V == 4) {
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<V4 *>(p)[i] = V4{v[0], v[1], v[2], v[3]};
+  } else {
+    p[i] = v[0];
+  }
+}
+
+template <typename T, int OP, int V>  // V values per thread per step (4 = 16-byte accesses)
+__global__ void __launch_bounds__(256)
+complex_op_kernel(const T *__restrict__ are, const T *__restrict__ aim, const T *__restrict__ bre,
+                  const T *__restrict__ bim, T sre, T sim, T *__restrict__ ore, T *__restrict__ oim,
+                  long long count, long long b_len) {
+  constexpr bool kBinary = OP <= kDiv;
+  const long long nvec = count / V;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += step) {
+    T ar[V], ai[V], br[V], bi[V], orr[V], oi[V];
+    ld_vec<T, V>(are, i, ar);
+    ld_vec<T, V>(aim, i, ai);
+    if constexpr (kBinary) {
+      const long long j = b_len == count ? i : ((i * V) % b_len) / V;  // b_len % V == 0 on this path
+      ld_vec<T, V>(bre, j, br);
+      ld_vec<T, V>(bim, j, bi);
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      complex_op1<T, OP>(ar[v], ai[v], kBinary ? br[v] : sre, kBinary ? bi[v] : sim, orr[v], oi[v]);
+    st_vec<T, V>(ore, i, orr);
+    st_vec<T, V>(oim, i, oi);
+  }
+}
+
 // SpectrumPeak per frame from stored amplitude (and phase) rows: the fallback of the fused
 // PEAK path for sizes / alignments the packed kernel does not take.  One workgroup per row.
 template <typename T>

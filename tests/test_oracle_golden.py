@@ -207,3 +207,20 @@ def test_numpy_cross_check_windowed_spectrum(oracle_mod, window):
     plan = oracle_mod.Plan(512)
     a2, p2, k2 = plan.spectrum_batch(frame[None, :], window=oracle_mod.create_window(window, 512), want_phase=True, want_peak=True)
     assert np.array_equal(a2[0], r["amplitude"]) and np.array_equal(p2[0], r["phase"]) and k2[0] == r["peak"]["index"]
+
+
+def test_complex_ops_known_answers(oracle_mod):
+    """test/math/complex.test.ts known answers: (1+2i)(3+4i) = -5+10i etc."""
+    r, i = oracle_mod.complex_op("mul", [1.0], [2.0], [3.0], [4.0])
+    assert (r[0], i[0]) == (-5.0, 10.0)
+    r, i = oracle_mod.complex_op("div", [-5.0], [10.0], [3.0], [4.0])
+    assert abs(r[0] - 1) < 1e-15 and abs(i[0] - 2) < 1e-15
+    r, i = oracle_mod.complex_op("conj", [1.0, -2.0], [3.0, 4.0])
+    assert list(r) == [1.0, -2.0] and list(i) == [-3.0, -4.0]
+    r, i = oracle_mod.complex_op("scale", [1.0, 2.0], [3.0, 4.0], s_re=2.0)
+    assert list(r) == [2.0, 4.0] and list(i) == [6.0, 8.0]
+    r, i = oracle_mod.complex_op("mulScalar", [1.0], [2.0], s_re=3.0, s_im=4.0)
+    assert (r[0], i[0]) == (-5.0, 10.0)
+    a = np.arange(6.0)
+    r, i = oracle_mod.complex_op("add", a, -a, [1.0, 2.0], [10.0, 20.0])  # row broadcast, period 2
+    assert list(r) == [1, 3, 3, 5, 5, 7] and list(i) == [10, 19, 8, 17, 6, 15]
