@@ -9,6 +9,17 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# ONE HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (SONAME
+# libamdhip64.so.7) and pulls it in by file name; libpdsp_hip.so needs "libamdhip64.so.7".
+# Loaded after torch, ours resolves onto torch's already-mapped copy by SONAME.  Loaded
+# BEFORE torch, the system copy is mapped first and torch then maps a second runtime: device
+# pointers would still work, but streams/events would not be shared, and whichever runtime
+# initialises second can fail ("no HIP device").  So torch, when present, is imported first.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pure drop-in use without torch: the system runtime is the only one
+    pass
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpdsp_hip.so")
 

@@ -291,8 +291,12 @@ int plan_window(pdsp_plan *plan, int type, const float **out) {
 
 int require_device() {
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-    return fail(PDSP_ERR_DEVICE, "no HIP device available (the pdsp engine has no CPU fallback)");
+  const hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return fail(PDSP_ERR_DEVICE, "no HIP device available (the pdsp engine has no CPU fallback) [hipGetDeviceCount: %s, %d]",
+                hipGetErrorString(e), count);
+  }
   return PDSP_OK;
 }
 
