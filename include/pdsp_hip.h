@@ -88,8 +88,17 @@ PDSP_API int pdsp_version(void);
 PDSP_API const char *pdsp_last_error(void);
 /* Number of visible HIP devices (0 when there is none); never fails. */
 PDSP_API int pdsp_device_count(void);
-/* Largest N the single-pass kernels take for 4-byte / 8-byte scalars. */
+/* Largest N the single-pass complex kernels take for 4-byte / 8-byte scalars (16384 / 8192;
+ * the real-frame spectrum path runs an N/2-point transform, so it takes N up to 16384 in f64). */
 PDSP_API int pdsp_max_size(int scalar_bytes);
+
+/* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).
+ *   64 (default): f64 on the device wherever the single-pass kernels hold the size -- the drop-in
+ *       then meets the reference's own test tolerances (1e-10 against NumPy, signals.test.ts:22-23),
+ *       not just the f32 contract; sizes beyond (complex N = 16384) compute in f32.
+ *   32: always f32 (the north-star's stated contract, max|err|/max|X| <= 1e-5).
+ * PDSP_HOST_PRECISION=32 in the environment presets it. */
+PDSP_API int pdsp_set_host_precision(int bits);
 
 /* ---- host-side index math (no device) --------------------------------- */
 
@@ -204,12 +213,36 @@ PDSP_API int pdsp_spectrum_peaks_f32(const pdsp_plan *plan, long long batch,
                                      float *amp_out, float *phase_out, pdsp_peak32 *peaks_out,
                                      pdsp_stream stream);
 
+/* ---- the same device-pointer family in f64 ------------------------------ */
+/* Identical contracts with double rows.  Complex transforms: N <= 8192; pdsp_spectrum_f64:
+ * N <= 16384 (PDSP_ERR_UNSUPPORTED_SIZE beyond).  ~1e-15 relative to max vs the f64 reference. */
+PDSP_API int pdsp_fft_forward_real_f64(const pdsp_plan *plan, long long batch,
+                                       const double *re_in, double *re_out, double *im_out,
+                                       pdsp_stream stream);
+PDSP_API int pdsp_fft_forward_complex_f64(const pdsp_plan *plan, long long batch,
+                                          const double *re_in, const double *im_in,
+                                          double *re_out, double *im_out, pdsp_stream stream);
+PDSP_API int pdsp_fft_inverse_f64(const pdsp_plan *plan, long long batch,
+                                  const double *re_in, const double *im_in,
+                                  double *re_out, double *im_out, pdsp_stream stream);
+PDSP_API int pdsp_apply_window_f64(long long batch, long long n, const double *in,
+                                   const double *window, double *out, pdsp_stream stream);
+PDSP_API int pdsp_magnitude_f64(long long count, const double *re, const double *im,
+                                double *out, pdsp_stream stream);
+PDSP_API int pdsp_phase_f64(long long count, const double *re, const double *im,
+                            double *out, pdsp_stream stream);
+PDSP_API int pdsp_spectrum_f64(const pdsp_plan *plan, long long batch,
+                               const double *frames, long long frame_len, long long frame_stride,
+                               const double *window, int sides,
+                               double *amp_out, double *phase_out, int32_t *peak_out,
+                               pdsp_stream stream);
+
 /* ---- host f64 drop-in entry points (synchronous) ----------------------- */
 
 /* Radix2Fft.transform, src/core/fft.ts:89-151, for `batch` rows.  im_in may be
  * NULL (= forward(real)).  in_len is the caller's row length and must equal N
- * (PDSP_ERR_INPUT_LENGTH otherwise, message as fft.ts:95-104).  Computes in f32
- * on the device (f64 at the boundary, SURVEY section 8 conventions). */
+ * (PDSP_ERR_INPUT_LENGTH otherwise, message as fft.ts:95-104).  Computes on the
+ * device in the precision pdsp_set_host_precision() selects (f64 at the boundary either way). */
 PDSP_API int pdsp_fft_transform_host_f64(pdsp_plan *plan, long long batch, long long in_len,
                                          const double *re_in, const double *im_in,
                                          double *re_out, double *im_out, int inverse);

@@ -67,6 +67,7 @@ def _load() -> C.CDLL:
         "pdsp_last_error": ([], C.c_char_p),
         "pdsp_device_count": ([], i32),
         "pdsp_max_size": ([i32], i32),
+        "pdsp_set_host_precision": ([i32], i32),
         "pdsp_is_pow2": ([ll], i32),
         "pdsp_next_pow2": ([ll], ll),
         "pdsp_window_make": ([i32, ll, dp], i32),
@@ -86,6 +87,13 @@ def _load() -> C.CDLL:
         "pdsp_phase_f32": ([ll, vp, vp, vp, vp], i32),
         "pdsp_complex_op_f32": ([i32, ll, vp, vp, vp, vp, ll, dbl, dbl, vp, vp, vp], i32),
         "pdsp_spectrum_f32": ([vp, ll, vp, ll, ll, vp, i32, vp, vp, vp, vp], i32),
+        "pdsp_fft_forward_real_f64": ([vp, ll, vp, vp, vp, vp], i32),
+        "pdsp_fft_forward_complex_f64": ([vp, ll, vp, vp, vp, vp, vp], i32),
+        "pdsp_fft_inverse_f64": ([vp, ll, vp, vp, vp, vp, vp], i32),
+        "pdsp_apply_window_f64": ([ll, ll, vp, vp, vp, vp], i32),
+        "pdsp_magnitude_f64": ([ll, vp, vp, vp, vp], i32),
+        "pdsp_phase_f64": ([ll, vp, vp, vp, vp], i32),
+        "pdsp_spectrum_f64": ([vp, ll, vp, ll, ll, vp, i32, vp, vp, vp, vp], i32),
         "pdsp_spectrum_peaks_f32": ([vp, ll, vp, ll, ll, vp, i32, dbl, vp, vp, vp, vp], i32),
         "pdsp_fft_transform_host_f64": ([vp, ll, ll, dp, dp, dp, dp, i32], i32),
         "pdsp_apply_window_host_f64": ([dp, ll, dp, ll, dp], i32),

@@ -28,9 +28,15 @@ def _ptr(t) -> C.c_void_p:
 
 
 class BatchedFft:
-    """One plan, many rows.  Tensors are float32, contiguous, shape [..., N], on the plan's GPU."""
+    """One plan, many rows.  Tensors are contiguous, shape [..., N], on the plan's GPU, of the
+    plan's dtype: torch.float32 (default; every size up to 16384) or torch.float64 (complex
+    transforms up to N = 8192, spectrum up to N = 16384)."""
 
-    def __init__(self, size, device=None):
+    def __init__(self, size, device=None, dtype=torch.float32):
+        if dtype not in (torch.float32, torch.float64):
+            raise PdspError(_capi.ERR_BAD_ARG, f"unsupported dtype {dtype}")
+        self.dtype = dtype
+        self._sfx = "f32" if dtype == torch.float32 else "f64"
         if not isPowerOfTwo(size):
             raise PdspError(_capi.ERR_SIZE_NOT_POW2, f"FFT size must be power of two, got {js_num(size)}")
         if not torch.cuda.is_available():
@@ -55,8 +61,8 @@ class BatchedFft:
 
     # -- helpers -------------------------------------------------------------
     def _check(self, t, name, last=None):
-        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
-            raise PdspError(_capi.ERR_BAD_ARG, f"{name} must be a contiguous float32 tensor on {self.device}")
+        if t.dtype != self.dtype or not t.is_cuda or not t.is_contiguous():
+            raise PdspError(_capi.ERR_BAD_ARG, f"{name} must be a contiguous {self.dtype} tensor on {self.device}")
         if t.device != self.device:
             raise PdspError(_capi.ERR_BAD_ARG, f"{name} is on {t.device}, plan is on {self.device}")
         want = self.size if last is None else last
@@ -76,7 +82,7 @@ class BatchedFft:
         FourierLive's window cache (src/effect/index.ts:39-48)."""
         w = self._windows.get(kind)
         if w is None:
-            w = torch.from_numpy(createWindow(kind, self.size).astype(np.float32)).to(self.device)
+            w = torch.from_numpy(createWindow(kind, self.size)).to(self.dtype).to(self.device)
             self._windows[kind] = w
         return w
 
@@ -88,10 +94,11 @@ class BatchedFft:
         ore, oim = self._out(re, out)
         s = _stream_ptr(self.device)
         if im is None:
-            check(lib.pdsp_fft_forward_real_f32(self._h, batch, _ptr(re), _ptr(ore), _ptr(oim), s))
+            check(getattr(lib, "pdsp_fft_forward_real_" + self._sfx)(self._h, batch, _ptr(re), _ptr(ore), _ptr(oim), s))
         else:
             self._check(im, "input.imag")
-            check(lib.pdsp_fft_forward_complex_f32(self._h, batch, _ptr(re), _ptr(im), _ptr(ore), _ptr(oim), s))
+            check(getattr(lib, "pdsp_fft_forward_complex_" + self._sfx)(self._h, batch, _ptr(re), _ptr(im), _ptr(ore),
+                                                                      _ptr(oim), s))
         return ore, oim
 
     def inverse(self, re: torch.Tensor, im: torch.Tensor, out=None):
@@ -99,16 +106,16 @@ class BatchedFft:
         self._check(im, "input.imag")
         batch = re.numel() // self.size
         ore, oim = self._out(re, out)
-        check(lib.pdsp_fft_inverse_f32(self._h, batch, _ptr(re), _ptr(im), _ptr(ore), _ptr(oim),
-                                       _stream_ptr(self.device)))
+        check(getattr(lib, "pdsp_fft_inverse_" + self._sfx)(self._h, batch, _ptr(re), _ptr(im), _ptr(ore), _ptr(oim),
+                                                          _stream_ptr(self.device)))
         return ore, oim
 
     def spectrum(self, frames: torch.Tensor, window="rect", sides: str = "one", want_phase: bool = False,
                  want_peak: bool = False, out=None):
         """Rows of spectrum()'s body: frames [..., L] (L <= N zero-padded, L > N
         truncated: spectrum.ts:36-43) -> amplitude [..., bins] (+ phase, + peak bin)."""
-        if frames.dtype != torch.float32 or not frames.is_cuda or not frames.is_contiguous():
-            raise PdspError(_capi.ERR_BAD_ARG, "frames must be a contiguous float32 CUDA tensor")
+        if frames.dtype != self.dtype or not frames.is_cuda or not frames.is_contiguous():
+            raise PdspError(_capi.ERR_BAD_ARG, f"frames must be a contiguous {self.dtype} CUDA tensor")
         length = frames.shape[-1]
         batch = frames.numel() // length if length else 0
         two = sides != "one"
@@ -124,10 +131,10 @@ class BatchedFft:
                     raise PdspError(_capi.ERR_WINDOW_LENGTH, "Window length must match input length.")
                 self._check(win, "window")
         shape = tuple(frames.shape[:-1])
-        amp = out if out is not None else torch.empty(shape + (bins,), dtype=torch.float32, device=self.device)
-        ph = torch.empty(shape + (bins,), dtype=torch.float32, device=self.device) if want_phase else None
+        amp = out if out is not None else torch.empty(shape + (bins,), dtype=self.dtype, device=self.device)
+        ph = torch.empty(shape + (bins,), dtype=self.dtype, device=self.device) if want_phase else None
         pk = torch.empty(shape, dtype=torch.int32, device=self.device) if want_peak else None
-        check(lib.pdsp_spectrum_f32(self._h, batch, _ptr(frames), min(length, self.size), length, _ptr(win),
+        check(getattr(lib, "pdsp_spectrum_" + self._sfx)(self._h, batch, _ptr(frames), min(length, self.size), length, _ptr(win),
                                     1 if two else 0, _ptr(amp), _ptr(ph), _ptr(pk), _stream_ptr(self.device)))
         return amp, ph, pk
 
@@ -138,6 +145,8 @@ class BatchedFft:
         (findPeak fused into the kernel).  Returns (index int32 [...], frequency, amplitude,
         phase float32 [...], amp-or-None, phase-or-None); with want_amp=False only 16 bytes
         per frame leave the kernel."""
+        if self.dtype != torch.float32:
+            raise PdspError(_capi.ERR_BAD_ARG, "spectrum_peaks is f32 only (16-byte f32 records)")
         if frames.dtype != torch.float32 or not frames.is_cuda or not frames.is_contiguous():
             raise PdspError(_capi.ERR_BAD_ARG, "frames must be a contiguous float32 CUDA tensor")
         if sample_rate <= 0:

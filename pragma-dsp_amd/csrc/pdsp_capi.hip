@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -64,24 +65,50 @@ int ilog2ll(long long n) {
 
 }  // namespace
 
+// Device tables of one precision.
+template <typename T>
+struct Tables {
+  using T2 = typename pdsp::vec2<T>::type;
+  T2 *tw = nullptr;       // inter-pass twiddles of the N-point transform (pdsp_radix.h layout)
+  // packed-real spectrum path (N >= 64): radix table of the N/2-point transform and the
+  // split twiddles W_N^k, 0 <= k <= N/4
+  T2 *tw_half = nullptr;
+  T2 *twr = nullptr;
+  T *win[4] = {nullptr, nullptr, nullptr, nullptr};  // createWindow(type, N), built on first use
+  void release() {
+    if (tw) (void)hipFree(tw);
+    if (tw_half) (void)hipFree(tw_half);
+    if (twr) (void)hipFree(twr);
+    for (T *&w : win) {
+      if (w) (void)hipFree(w);
+      w = nullptr;
+    }
+    tw = tw_half = twr = nullptr;
+  }
+};
+
 struct pdsp_plan {
   long long n = 0;
   int log2n = 0;
   int device = -1;
-  float2 *d_tw32 = nullptr;
-  // packed-real spectrum path (N >= 64): radix table of the N/2-point transform and
-  // the split twiddles W_N^k, 0 <= k <= N/4
-  float2 *d_tw32_half = nullptr;
-  float2 *d_twr32 = nullptr;
+  Tables<float> t32;
+  Tables<double> t64;  // present when the f64 single-pass kernels take this size
   // host-f64 entry points: one stream + growing staging buffers per plan
   std::mutex mu;
   hipStream_t stream = nullptr;
-  float *h_stage = nullptr;  // pinned
-  size_t h_floats = 0;
-  float *d_stage = nullptr;
-  size_t d_floats = 0;
-  float *d_win[4] = {nullptr, nullptr, nullptr, nullptr};
+  void *h_stage = nullptr;  // pinned
+  size_t h_bytes = 0;
+  void *d_stage = nullptr;
+  size_t d_bytes = 0;
 };
+
+template <typename T> Tables<T> &tables(pdsp_plan *p);
+template <> Tables<float> &tables<float>(pdsp_plan *p) { return p->t32; }
+template <> Tables<double> &tables<double>(pdsp_plan *p) { return p->t64; }
+template <typename T> const Tables<T> &tables(const pdsp_plan *p) { return tables<T>(const_cast<pdsp_plan *>(p)); }
+
+// Largest log2 N of the single-pass kernels: (N + N/16) complex values must fit 160 KiB of LDS.
+template <typename T> constexpr int max_log2n() { return sizeof(T) == 4 ? pdsp::kMaxLog2N_f32 : pdsp::kMaxLog2N_f64; }
 
 namespace {
 
@@ -108,21 +135,27 @@ std::vector<T2> build_twiddles(int log2n) {
   return tw;
 }
 
-template <int LOG2N, class LD, class ST>
-hipError_t launch_one(const LD &ld, const ST &st, const float2 *tw, long long batch, hipStream_t s) {
-  using TR = pdsp::FftTraits<LOG2N>;
-  const long long blocks = (batch + TR::ROWS - 1) / TR::ROWS;
-  hipLaunchKernelGGL((pdsp::fft_stockham_kernel<float, LOG2N, LD, ST>), dim3((unsigned)blocks), dim3(TR::WG), 0,
-                     s, ld, st, tw, batch);
-  return hipGetLastError();
+template <typename T, int LOG2N, class LD, class ST>
+hipError_t launch_one(const LD &ld, const ST &st, const typename pdsp::vec2<T>::type *tw, long long batch,
+                      hipStream_t s) {
+  if constexpr (LOG2N > max_log2n<T>()) {
+    return hipErrorInvalidValue;  // would not fit LDS; never instantiated
+  } else {
+    using TR = pdsp::FftTraits<LOG2N>;
+    const long long blocks = (batch + TR::ROWS - 1) / TR::ROWS;
+    hipLaunchKernelGGL((pdsp::fft_stockham_kernel<T, LOG2N, LD, ST>), dim3((unsigned)blocks), dim3(TR::WG), 0, s, ld,
+                       st, tw, batch);
+    return hipGetLastError();
+  }
 }
 
-template <class LD, class ST>
-hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, long long batch, hipStream_t s) {
+template <typename T, class LD, class ST>
+hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const typename pdsp::vec2<T>::type *tw, long long batch,
+                      hipStream_t s) {
   switch (log2n) {
 #define PDSP_CASE(L) \
   case L:            \
-    return launch_one<L>(ld, st, tw, batch, s);
+    return launch_one<T, L>(ld, st, tw, batch, s);
     PDSP_CASE(0) PDSP_CASE(1) PDSP_CASE(2) PDSP_CASE(3) PDSP_CASE(4) PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7)
     PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12) PDSP_CASE(13) PDSP_CASE(14)
 #undef PDSP_CASE
@@ -131,21 +164,26 @@ hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const float2 *tw, l
   }
 }
 
-template <int LOG2M>
-hipError_t launch_packed_one(bool fast, const float *frames, const float *win, long long frame_len, long long stride,
-                             const float2 *tw, const float2 *twr, float *amp, float *ph, int two_sided, float s_edge,
-                             float s_mid, pdsp::PeakRec *peaks, float freq_scale, long long batch, hipStream_t s) {
+template <typename T, int LOG2M>
+hipError_t launch_packed_one(bool fast, const T *frames, const T *win, long long frame_len, long long stride,
+                             const typename pdsp::vec2<T>::type *tw, const typename pdsp::vec2<T>::type *twr, T *amp,
+                             T *ph, int two_sided, T s_edge, T s_mid, pdsp::PeakRec *peaks, T freq_scale,
+                             long long batch, hipStream_t s) {
   using TR = pdsp::FftTraits<LOG2M>;
   const long long ngroups = (batch + TR::ROWS - 1) / TR::ROWS;
   const dim3 block(TR::WG);
-#define PDSP_LAUNCH(F, W, P)                                                                                      \
-  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, LOG2M, F, W, P>), dim3((unsigned)ngroups), block, 0, s, \
+#define PDSP_LAUNCH(F, W, P)                                                                                  \
+  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<T, LOG2M, F, W, P>), dim3((unsigned)ngroups), block, 0, s, \
                      frames, win, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, peaks, freq_scale, \
                      batch)
-#define PDSP_LAUNCH_FW(F, W)     \
-  do {                           \
-    if (peaks) PDSP_LAUNCH(F, W, true); \
-    else PDSP_LAUNCH(F, W, false);      \
+#define PDSP_LAUNCH_FW(F, W)                            \
+  do {                                                  \
+    if constexpr (sizeof(T) == 4) {                     \
+      if (peaks) PDSP_LAUNCH(F, W, true);               \
+      else PDSP_LAUNCH(F, W, false);                    \
+    } else {                                            \
+      PDSP_LAUNCH(F, W, false); /* fused peaks: f32 only */ \
+    }                                                   \
   } while (0)
   if (fast && win) PDSP_LAUNCH_FW(true, true);
   else if (fast) PDSP_LAUNCH_FW(true, false);
@@ -156,12 +194,12 @@ hipError_t launch_packed_one(bool fast, const float *frames, const float *win, l
   return hipGetLastError();
 }
 
-template <class... A>
+template <typename T, class... A>
 hipError_t launch_packed(int log2m, A... a) {
   switch (log2m) {
 #define PDSP_CASE(L) \
   case L:            \
-    return launch_packed_one<L>(a...);
+    return launch_packed_one<T, L>(a...);
     PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7) PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12)
     PDSP_CASE(13)
 #undef PDSP_CASE
@@ -178,19 +216,26 @@ int check_plan_batch(const pdsp_plan *plan, long long batch) {
   return PDSP_OK;
 }
 
-int run_complex(const pdsp_plan *plan, long long batch, const float *re_in, const float *im_in, float *re_out,
-                float *im_out, float scale, hipStream_t s) {
+template <typename T>
+int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out, T scale,
+                hipStream_t s) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
   if (batch == 0) return PDSP_OK;
+  if (!re_in || !re_out || !im_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  const Tables<T> &t = tables<T>(plan);
+  if (!t.tw)
+    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit single-pass limit %d", plan->n,
+                (int)(8 * sizeof(T)), 1 << max_log2n<T>());
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
   hipError_t e;
-  pdsp::StoreComplex<float> st{re_out, im_out, plan->n, scale};
+  pdsp::StoreComplex<T> st{re_out, im_out, plan->n, scale};
   if (im_in) {
-    pdsp::LoadComplex<float> ld{re_in, im_in, plan->n};
-    e = launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, s);
+    pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};
+    e = launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s);
   } else {
-    pdsp::LoadReal<float> ld{re_in, plan->n};
-    e = launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, s);
+    pdsp::LoadReal<T> ld{re_in, plan->n};
+    e = launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s);
   }
   PDSP_HIP_TRY(e);
   return PDSP_OK;
@@ -203,37 +248,36 @@ int grid_for(long long total) {
   return (int)b;
 }
 
-int ensure_stage(pdsp_plan *plan, size_t floats) {
+int ensure_stage(pdsp_plan *plan, size_t bytes) {
   if (!plan->stream) PDSP_HIP_TRY(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking));
-  if (plan->h_floats < floats) {
+  if (plan->h_bytes < bytes) {
     if (plan->h_stage) (void)hipHostFree(plan->h_stage);
     plan->h_stage = nullptr;
-    plan->h_floats = 0;
-    PDSP_HIP_TRY(hipHostMalloc((void **)&plan->h_stage, floats * sizeof(float), hipHostMallocDefault));
-    plan->h_floats = floats;
+    plan->h_bytes = 0;
+    PDSP_HIP_TRY(hipHostMalloc(&plan->h_stage, bytes, hipHostMallocDefault));
+    plan->h_bytes = bytes;
   }
-  if (plan->d_floats < floats) {
+  if (plan->d_bytes < bytes) {
     if (plan->d_stage) (void)hipFree(plan->d_stage);
     plan->d_stage = nullptr;
-    plan->d_floats = 0;
-    PDSP_HIP_TRY(hipMalloc((void **)&plan->d_stage, floats * sizeof(float)));
-    plan->d_floats = floats;
+    plan->d_bytes = 0;
+    PDSP_HIP_TRY(hipMalloc(&plan->d_stage, bytes));
+    plan->d_bytes = bytes;
   }
   return PDSP_OK;
 }
 
 // Scratch (plan-less) staging for the element-wise host entry points.
+template <typename T>
 struct Scratch {
-  float *h = nullptr, *d = nullptr;
-  size_t n = 0;
+  T *h = nullptr, *d = nullptr;
   ~Scratch() {
     if (h) (void)hipHostFree(h);
     if (d) (void)hipFree(d);
   }
-  int reserve(size_t floats) {
-    PDSP_HIP_TRY(hipHostMalloc((void **)&h, floats * sizeof(float), hipHostMallocDefault));
-    PDSP_HIP_TRY(hipMalloc((void **)&d, floats * sizeof(float)));
-    n = floats;
+  int reserve(size_t count) {
+    PDSP_HIP_TRY(hipHostMalloc((void **)&h, count * sizeof(T), hipHostMallocDefault));
+    PDSP_HIP_TRY(hipMalloc((void **)&d, count * sizeof(T)));
     return PDSP_OK;
   }
 };
@@ -270,23 +314,63 @@ int cached_plan(long long n, pdsp_plan **out) {
   return PDSP_OK;
 }
 
-// Device copy (f32) of createWindow(type, N), built once per plan.  Caller holds plan->mu.
-int plan_window(pdsp_plan *plan, int type, const float **out) {
-  if (!plan->d_win[type]) {
+// Device copy of createWindow(type, N), built once per plan and precision (the window is
+// always computed in f64 on the host and rounded once).  Caller holds plan->mu.
+template <typename T>
+int plan_window(pdsp_plan *plan, int type, const T **out) {
+  Tables<T> &t = tables<T>(plan);
+  if (!t.win[type]) {
     std::vector<double> w((size_t)plan->n);
     if (int rc = pdsp_window_make(type, plan->n, w.data())) return rc;
-    std::vector<float> wf(w.begin(), w.end());
-    float *d = nullptr;
-    PDSP_HIP_TRY(hipMalloc((void **)&d, wf.size() * sizeof(float)));
-    hipError_t e = hipMemcpy(d, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice);
+    std::vector<T> wt(w.begin(), w.end());
+    T *d = nullptr;
+    PDSP_HIP_TRY(hipMalloc((void **)&d, wt.size() * sizeof(T)));
+    hipError_t e = hipMemcpy(d, wt.data(), wt.size() * sizeof(T), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(d);
       PDSP_HIP_TRY(e);
     }
-    plan->d_win[type] = d;
+    t.win[type] = d;
   }
-  *out = plan->d_win[type];
+  *out = t.win[type];
   return PDSP_OK;
+}
+
+// Precision of the host-f64 entry points: 64 (default) computes in f64 wherever the single-pass
+// kernels hold the size (complex N <= 8192, real spectrum N <= 16384) and in f32 beyond; 32 always
+// computes in f32 (the north-star's contract).  PDSP_HOST_PRECISION=32 in the environment presets it.
+int g_host_precision = 0;
+int host_precision() {
+  if (g_host_precision == 0) {
+    const char *e = getenv("PDSP_HOST_PRECISION");
+    g_host_precision = (e && atoi(e) == 32) ? 32 : 64;
+  }
+  return g_host_precision;
+}
+
+template <typename T>
+hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, bool half) {
+  using T2 = typename pdsp::vec2<T>::type;
+  hipError_t e = hipSuccess;
+  if (full) {
+    const std::vector<T2> tw = build_twiddles<T2>(log2n);
+    e = hipMalloc((void **)&t.tw, tw.size() * sizeof(T2));
+    if (e == hipSuccess) e = hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(T2), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && half) {
+    const std::vector<T2> twh = build_twiddles<T2>(log2n - 1);
+    std::vector<T2> twr((size_t)(size / 4 + 1));
+    for (long long k = 0; k <= size / 4; ++k) {
+      const double angle = (-2.0 * M_PI * (double)k) / (double)size;
+      twr[(size_t)k].x = (T)std::cos(angle);
+      twr[(size_t)k].y = (T)std::sin(angle);
+    }
+    e = hipMalloc((void **)&t.tw_half, twh.size() * sizeof(T2));
+    if (e == hipSuccess) e = hipMemcpy(t.tw_half, twh.data(), twh.size() * sizeof(T2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&t.twr, twr.size() * sizeof(T2));
+    if (e == hipSuccess) e = hipMemcpy(t.twr, twr.data(), twr.size() * sizeof(T2), hipMemcpyHostToDevice);
+  }
+  return e;
 }
 
 int require_device() {
@@ -317,6 +401,182 @@ int launch_complex_op(long long count, const float *are, const float *aim, const
   return PDSP_OK;
 }
 
+template <typename T>
+int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long long frame_len, long long frame_stride,
+                  const T *window, int sides, T *amp_out, T *phase_out, int32_t *peak_idx_out, pdsp_peak32 *peaks_out,
+                  double sample_rate, hipStream_t stream) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
+  if (frame_len < 0 || frame_stride < frame_len) return fail(PDSP_ERR_BAD_ARG, "bad frame_len/frame_stride");
+  if (peaks_out && sample_rate <= 0)
+    return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
+  if (batch == 0) return PDSP_OK;
+  if (!frames || (!amp_out && !peaks_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  if ((phase_out || peak_idx_out) && !amp_out) return fail(PDSP_ERR_BAD_ARG, "phase/peak index output needs amp_out");
+  const Tables<T> &t = tables<T>(plan);
+  if (!t.tw && !t.tw_half)
+    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit single-pass limit", plan->n,
+                (int)(8 * sizeof(T)));
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  static_assert(sizeof(pdsp_peak32) == sizeof(pdsp::PeakRec), "peak record layout");
+  const long long n = plan->n;
+  const int bins = (int)(sides == PDSP_SIDES_ONE ? n / 2 + 1 : n);
+  const long long used = frame_len < n ? frame_len : n;
+  const T freq_scale = peaks_out ? (T)(sample_rate / (double)n) : T(0);
+  if (used == 0) {  // an empty frame is all zeros: amplitude 0, atan2(0, 0) = 0, peak 0
+    if (amp_out) PDSP_HIP_TRY(hipMemsetAsync(amp_out, 0, (size_t)batch * bins * sizeof(T), stream));
+    if (phase_out) PDSP_HIP_TRY(hipMemsetAsync(phase_out, 0, (size_t)batch * bins * sizeof(T), stream));
+    if (peak_idx_out) PDSP_HIP_TRY(hipMemsetAsync(peak_idx_out, 0, (size_t)batch * sizeof(int32_t), stream));
+    if (peaks_out) PDSP_HIP_TRY(hipMemsetAsync(peaks_out, 0, (size_t)batch * sizeof(pdsp_peak32), stream));
+    return PDSP_OK;
+  }
+  const T s_edge = T(1) / (T)n, s_mid = (sides == PDSP_SIDES_ONE ? T(2) : T(1)) / (T)n;
+  constexpr uintptr_t kPairMask = 2 * sizeof(T) - 1;  // alignment of one (re, im) pair
+  if (t.tw_half && (window == nullptr || ((uintptr_t)window & kPairMask) == 0)) {
+    // packed-real path: N/2-point complex transform + Hermitian split (+ findPeak) fused with the store.
+    // fast variant: whole pair-aligned frames, one-sided, no phase rows (config 4's shape)
+    const bool fast = ((uintptr_t)frames & kPairMask) == 0 && (frame_stride & 1) == 0 && used == n &&
+                      sides == PDSP_SIDES_ONE && phase_out == nullptr;
+    PDSP_HIP_TRY(launch_packed<T>(plan->log2n - 1, fast, frames, window, used, frame_stride, t.tw_half, t.twr, amp_out,
+                                  phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
+                                  reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
+  } else {
+    // complex kernel on (x, 0) for N < 64 or an unaligned window; peaks come from the stored rows
+    if (!t.tw) return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unaligned window at a size only the packed path holds");
+    T *amp = amp_out, *ph = phase_out;
+    const size_t row_bytes = (size_t)batch * bins * sizeof(T);
+    if (peaks_out && !amp) PDSP_HIP_TRY(hipMallocAsync((void **)&amp, row_bytes, stream));
+    if (peaks_out && !ph) PDSP_HIP_TRY(hipMallocAsync((void **)&ph, row_bytes, stream));
+    pdsp::StoreAmplitude<T> st{amp, ph, bins,
+                               // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
+                               (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1, s_edge, s_mid};
+    if (window) {
+      pdsp::LoadFrameWindowed<T, true> ld{frames, window, used, frame_stride};
+      PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, stream));
+    } else {
+      pdsp::LoadFrameWindowed<T, false> ld{frames, window, used, frame_stride};
+      PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, stream));
+    }
+    if (peaks_out) {
+      hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph, bins,
+                         freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
+      PDSP_HIP_TRY(hipGetLastError());
+      if (!amp_out) PDSP_HIP_TRY(hipFreeAsync(amp, stream));
+      if (!phase_out) PDSP_HIP_TRY(hipFreeAsync(ph, stream));
+    }
+  }
+  if (peak_idx_out) {
+    hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
+                       peak_idx_out, batch);
+    PDSP_HIP_TRY(hipGetLastError());
+  }
+  return PDSP_OK;
+}
+
+// Radix2Fft.transform for `batch` host rows in precision T (f64 at the boundary either way).
+template <typename T>
+int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const double *im_in, double *re_out,
+                   double *im_out, int inverse) {
+  const size_t cnt = (size_t)batch * (size_t)plan->n;
+  if (int rc = ensure_stage(plan, 4 * cnt * sizeof(T))) return rc;
+  T *h_re = (T *)plan->h_stage, *h_im = h_re + cnt, *h_ore = h_im + cnt, *h_oim = h_ore + cnt;
+  T *d_re = (T *)plan->d_stage, *d_im = d_re + cnt, *d_ore = d_im + cnt, *d_oim = d_ore + cnt;
+  for (size_t i = 0; i < cnt; ++i) h_re[i] = (T)re_in[i];
+  if (im_in)
+    for (size_t i = 0; i < cnt; ++i) h_im[i] = (T)im_in[i];
+  hipStream_t s = plan->stream;
+  PDSP_HIP_TRY(hipMemcpyAsync(d_re, h_re, (im_in ? 2 : 1) * cnt * sizeof(T), hipMemcpyHostToDevice, s));
+  int rc;
+  // inverse: conj(FFT(conj(z))) == swap(FFT(swap(z))) -- the conjugated-twiddle sweep of fft.ts:122
+  // is the forward kernel with the planes exchanged on the way in and out; 1/N rides on the store
+  if (inverse) rc = run_complex<T>(plan, batch, d_im, d_re, d_oim, d_ore, T(1) / (T)plan->n, s);
+  else rc = run_complex<T>(plan, batch, d_re, im_in ? d_im : nullptr, d_ore, d_oim, T(1), s);
+  if (rc) return rc;
+  PDSP_HIP_TRY(hipMemcpyAsync(h_ore, d_ore, 2 * cnt * sizeof(T), hipMemcpyDeviceToHost, s));
+  PDSP_HIP_TRY(hipStreamSynchronize(s));
+  for (size_t i = 0; i < cnt; ++i) re_out[i] = (double)h_ore[i];
+  for (size_t i = 0; i < cnt; ++i) im_out[i] = (double)h_oim[i];
+  return PDSP_OK;
+}
+
+template <typename T>
+int apply_window_dev(long long batch, long long n, const T *in, const T *window, T *out, hipStream_t s) {
+  const long long total = batch * n;
+  if (total == 0) return PDSP_OK;
+  if (!in || !window || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  hipLaunchKernelGGL((pdsp::apply_window_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, in, window, out, total, n);
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
+template <typename T, bool PHASE>
+int polar_dev(long long count, const T *re, const T *im, T *out, hipStream_t s) {
+  if (count < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
+  if (count == 0) return PDSP_OK;
+  if (!re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  hipLaunchKernelGGL((pdsp::polar_kernel<T, PHASE>), dim3(grid_for(count)), dim3(256), 0, s, re, im, out, count);
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
+template <typename T>
+int apply_window_host(const double *in, long long n_, const double *window, double *out) {
+  Scratch<T> sc;
+  const size_t n = (size_t)n_;
+  if (int rc = sc.reserve(3 * n)) return rc;
+  for (size_t i = 0; i < n; ++i) sc.h[i] = (T)in[i];
+  for (size_t i = 0; i < n; ++i) sc.h[n + i] = (T)window[i];
+  PDSP_HIP_TRY(hipMemcpy(sc.d, sc.h, 2 * n * sizeof(T), hipMemcpyHostToDevice));
+  if (int rc = apply_window_dev<T>(1, n_, sc.d, sc.d + n, sc.d + 2 * n, nullptr)) return rc;
+  PDSP_HIP_TRY(hipMemcpy(sc.h, sc.d + 2 * n, n * sizeof(T), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) out[i] = (double)sc.h[i];
+  return PDSP_OK;
+}
+
+template <typename T>
+int polar_host_t(const double *re, const double *im, long long n_, double *out, bool want_phase) {
+  Scratch<T> sc;
+  const size_t n = (size_t)n_;
+  if (int rc = sc.reserve(3 * n)) return rc;
+  for (size_t i = 0; i < n; ++i) sc.h[i] = (T)re[i];
+  for (size_t i = 0; i < n; ++i) sc.h[n + i] = (T)im[i];
+  PDSP_HIP_TRY(hipMemcpy(sc.d, sc.h, 2 * n * sizeof(T), hipMemcpyHostToDevice));
+  const int rc = want_phase ? polar_dev<T, true>(n_, sc.d, sc.d + n, sc.d + 2 * n, nullptr)
+                            : polar_dev<T, false>(n_, sc.d, sc.d + n, sc.d + 2 * n, nullptr);
+  if (rc) return rc;
+  PDSP_HIP_TRY(hipMemcpy(sc.h, sc.d + 2 * n, n * sizeof(T), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) out[i] = (double)sc.h[i];
+  return PDSP_OK;
+}
+
+// The one frame of spectrum() in precision T; plan->mu held by the caller.
+template <typename T>
+int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int window, int sides, double *amp_out,
+                    double *phase_out) {
+  const long long n = plan->n;
+  const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
+  const long long used = len < n ? len : n;
+  // staging: [frame n][unused n][amp bins][phase bins]
+  if (int rc = ensure_stage(plan, (size_t)(2 * n + 2 * bins) * sizeof(T))) return rc;
+  T *h = (T *)plan->h_stage, *d = (T *)plan->d_stage;
+  for (long long i = 0; i < used; ++i) h[i] = (T)samples[i];
+  for (long long i = used; i < n; ++i) h[i] = T(0);
+  const T *d_window = nullptr;
+  if (n != 1 && window != PDSP_WIN_RECT) {
+    if (int rc = plan_window<T>(plan, window, &d_window)) return rc;
+  }
+  hipStream_t s = plan->stream;
+  PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(T), hipMemcpyHostToDevice, s));
+  if (int rc = spectrum_impl<T>(plan, 1, d, n, n, d_window, sides, d + 2 * n, d + 2 * n + bins, nullptr, nullptr, 1.0, s))
+    return rc;
+  PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * n, d + 2 * n, (size_t)(2 * bins) * sizeof(T), hipMemcpyDeviceToHost, s));
+  PDSP_HIP_TRY(hipStreamSynchronize(s));
+  for (long long i = 0; i < bins; ++i) amp_out[i] = (double)h[2 * n + i];
+  for (long long i = 0; i < bins; ++i) phase_out[i] = (double)h[2 * n + bins + i];
+  return PDSP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -336,7 +596,14 @@ int pdsp_device_count(void) {
 
 int pdsp_max_size(int scalar_bytes) {
   if (scalar_bytes == 4) return 1 << pdsp::kMaxLog2N_f32;
+  if (scalar_bytes == 8) return 1 << pdsp::kMaxLog2N_f64;
   return 0;
+}
+
+int pdsp_set_host_precision(int bits) {
+  const int prev = host_precision();
+  if (bits == 32 || bits == 64) g_host_precision = bits;
+  return prev;
 }
 
 /* ---- host index math ---------------------------------------------------- */
@@ -432,27 +699,17 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
   p->n = size;
   p->log2n = log2n;
   p->device = device;
-  const std::vector<float2> tw = build_twiddles<float2>(log2n);
-  hipError_t e = hipMalloc((void **)&p->d_tw32, tw.size() * sizeof(float2));
-  if (e == hipSuccess) e = hipMemcpy(p->d_tw32, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
-  if (e == hipSuccess && log2n >= 6) {
-    const std::vector<float2> twh = build_twiddles<float2>(log2n - 1);
-    std::vector<float2> twr((size_t)(size / 4 + 1));
-    for (long long k = 0; k <= size / 4; ++k) {
-      const double angle = (-2.0 * M_PI * (double)k) / (double)size;
-      twr[(size_t)k] = make_float2((float)std::cos(angle), (float)std::sin(angle));
-    }
-    e = hipMalloc((void **)&p->d_tw32_half, twh.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMemcpy(p->d_tw32_half, twh.data(), twh.size() * sizeof(float2), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_twr32, twr.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMemcpy(p->d_twr32, twr.data(), twr.size() * sizeof(float2), hipMemcpyHostToDevice);
-  }
+  hipError_t e = upload_tables<float>(p->t32, log2n, size, true, log2n >= 6);
+  // f64 tables wherever the f64 single-pass kernels hold the size: the complex transform up to
+  // 2^13 (LDS), the packed-real spectrum (an N/2-point transform) up to N = 2^14
+  if (e == hipSuccess)
+    e = upload_tables<double>(p->t64, log2n, size, log2n <= pdsp::kMaxLog2N_f64,
+                              log2n >= 6 && log2n - 1 <= pdsp::kMaxLog2N_f64);
   if (e != hipSuccess) {
-    if (p->d_tw32) (void)hipFree(p->d_tw32);
-    if (p->d_tw32_half) (void)hipFree(p->d_tw32_half);
-    if (p->d_twr32) (void)hipFree(p->d_twr32);
+    p->t32.release();
+    p->t64.release();
     delete p;
-    return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) while uploading the twiddle table", (int)e, hipGetErrorString(e));
+    return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) while uploading the twiddle tables", (int)e, hipGetErrorString(e));
   }
   *plan_out = p;
   return PDSP_OK;
@@ -474,13 +731,10 @@ int pdsp_plan_destroy(pdsp_plan *plan) {
       (void)hipStreamSynchronize(plan->stream);
       (void)hipStreamDestroy(plan->stream);
     }
-    if (plan->d_tw32) (void)hipFree(plan->d_tw32);
-    if (plan->d_tw32_half) (void)hipFree(plan->d_tw32_half);
-    if (plan->d_twr32) (void)hipFree(plan->d_twr32);
+    plan->t32.release();
+    plan->t64.release();
     if (plan->d_stage) (void)hipFree(plan->d_stage);
     if (plan->h_stage) (void)hipHostFree(plan->h_stage);
-    for (float *w : plan->d_win)
-      if (w) (void)hipFree(w);
   }
   delete plan;
   return PDSP_OK;
@@ -491,63 +745,46 @@ int pdsp_plan_device(const pdsp_plan *plan) { return plan ? plan->device : -1; }
 
 /* ---- device-pointer transforms --------------------------------------------- */
 
-int pdsp_fft_forward_real_f32(const pdsp_plan *plan, long long batch, const float *re_in, float *re_out,
-                              float *im_out, pdsp_stream stream) {
-  if (int rc = check_plan_batch(plan, batch)) return rc;
-  if (batch && (!re_in || !re_out || !im_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  return run_complex(plan, batch, re_in, nullptr, re_out, im_out, 1.0f, (hipStream_t)stream);
-}
+#define PDSP_DEFINE_TRANSFORMS(SUFFIX, T)                                                                          \
+  int pdsp_fft_forward_real_##SUFFIX(const pdsp_plan *plan, long long batch, const T *re_in, T *re_out, T *im_out, \
+                                     pdsp_stream stream) {                                                         \
+    return run_complex<T>(plan, batch, re_in, nullptr, re_out, im_out, T(1), (hipStream_t)stream);                 \
+  }                                                                                                                \
+  int pdsp_fft_forward_complex_##SUFFIX(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in,    \
+                                        T *re_out, T *im_out, pdsp_stream stream) {                                \
+    if (batch > 0 && !im_in) return fail(PDSP_ERR_BAD_ARG, "null buffer");                                         \
+    return run_complex<T>(plan, batch, re_in, im_in, re_out, im_out, T(1), (hipStream_t)stream);                   \
+  }                                                                                                                \
+  /* conj(FFT(conj(z))) == swap(FFT(swap(z))): the conjugated-twiddle sweep of fft.ts:122 is the forward */        \
+  /* kernel with the planes exchanged on the way in and out; the 1/N of fft.ts:142-148 rides on the store */       \
+  int pdsp_fft_inverse_##SUFFIX(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, \
+                                T *im_out, pdsp_stream stream) {                                                   \
+    if (!plan) return fail(PDSP_ERR_BAD_ARG, "plan is null");                                                      \
+    if (batch > 0 && !re_in) return fail(PDSP_ERR_BAD_ARG, "null buffer");                                         \
+    return run_complex<T>(plan, batch, im_in, re_in, im_out, re_out, T(1) / (T)plan->n, (hipStream_t)stream);      \
+  }                                                                                                                \
+  int pdsp_apply_window_##SUFFIX(long long batch, long long n, const T *in, const T *window, T *out,               \
+                                 pdsp_stream stream) {                                                             \
+    if (batch < 0 || n < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");                                        \
+    return apply_window_dev<T>(batch, n, in, window, out, (hipStream_t)stream);                                    \
+  }                                                                                                                \
+  int pdsp_magnitude_##SUFFIX(long long count, const T *re, const T *im, T *out, pdsp_stream stream) {             \
+    return polar_dev<T, false>(count, re, im, out, (hipStream_t)stream);                                           \
+  }                                                                                                                \
+  int pdsp_phase_##SUFFIX(long long count, const T *re, const T *im, T *out, pdsp_stream stream) {                 \
+    return polar_dev<T, true>(count, re, im, out, (hipStream_t)stream);                                            \
+  }                                                                                                                \
+  int pdsp_spectrum_##SUFFIX(const pdsp_plan *plan, long long batch, const T *frames, long long frame_len,         \
+                             long long frame_stride, const T *window, int sides, T *amp_out, T *phase_out,         \
+                             int32_t *peak_out, pdsp_stream stream) {                                              \
+    if (batch > 0 && !amp_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");                                       \
+    return spectrum_impl<T>(plan, batch, frames, frame_len, frame_stride, window, sides, amp_out, phase_out,       \
+                            peak_out, nullptr, 1.0, (hipStream_t)stream);                                          \
+  }
 
-int pdsp_fft_forward_complex_f32(const pdsp_plan *plan, long long batch, const float *re_in, const float *im_in,
-                                 float *re_out, float *im_out, pdsp_stream stream) {
-  if (int rc = check_plan_batch(plan, batch)) return rc;
-  if (batch && (!re_in || !im_in || !re_out || !im_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  return run_complex(plan, batch, re_in, im_in, re_out, im_out, 1.0f, (hipStream_t)stream);
-}
-
-int pdsp_fft_inverse_f32(const pdsp_plan *plan, long long batch, const float *re_in, const float *im_in,
-                         float *re_out, float *im_out, pdsp_stream stream) {
-  if (int rc = check_plan_batch(plan, batch)) return rc;
-  if (batch && (!re_in || !im_in || !re_out || !im_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  // conj(FFT(conj(z))) == swap(FFT(swap(z))): the conjugated-twiddle sweep of
-  // fft.ts:122 is the forward kernel with the planes exchanged on the way in and
-  // out; the 1/N of fft.ts:142-148 rides on the store.
-  return run_complex(plan, batch, im_in, re_in, im_out, re_out, 1.0f / (float)plan->n, (hipStream_t)stream);
-}
-
-/* ---- device-pointer element-wise helpers ----------------------------------- */
-
-int pdsp_apply_window_f32(long long batch, long long n, const float *in, const float *window, float *out,
-                          pdsp_stream stream) {
-  if (batch < 0 || n < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
-  const long long total = batch * n;
-  if (total == 0) return PDSP_OK;
-  if (!in || !window || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  hipLaunchKernelGGL((pdsp::apply_window_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     in, window, out, total, n);
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
-
-int pdsp_magnitude_f32(long long count, const float *re, const float *im, float *out, pdsp_stream stream) {
-  if (count < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
-  if (count == 0) return PDSP_OK;
-  if (!re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  hipLaunchKernelGGL((pdsp::polar_kernel<float, false>), dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
-                     re, im, out, count);
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
-
-int pdsp_phase_f32(long long count, const float *re, const float *im, float *out, pdsp_stream stream) {
-  if (count < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
-  if (count == 0) return PDSP_OK;
-  if (!re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  hipLaunchKernelGGL((pdsp::polar_kernel<float, true>), dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream,
-                     re, im, out, count);
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
+PDSP_DEFINE_TRANSFORMS(f32, float)
+PDSP_DEFINE_TRANSFORMS(f64, double)
+#undef PDSP_DEFINE_TRANSFORMS
 
 int pdsp_complex_op_f32(int op, long long count, const float *a_re, const float *a_im, const float *b_re,
                         const float *b_im, long long b_len, double s_re, double s_im, float *out_re, float *out_im,
@@ -575,88 +812,14 @@ int pdsp_complex_op_f32(int op, long long count, const float *a_re, const float 
   }
 }
 
-/* ---- fused spectrum ---------------------------------------------------------- */
-
-static int spectrum_impl(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
-                         long long frame_stride, const float *window, int sides, float *amp_out, float *phase_out,
-                         int32_t *peak_idx_out, pdsp_peak32 *peaks_out, double sample_rate, hipStream_t stream) {
-  if (int rc = check_plan_batch(plan, batch)) return rc;
-  if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
-  if (frame_len < 0 || frame_stride < frame_len) return fail(PDSP_ERR_BAD_ARG, "bad frame_len/frame_stride");
-  if (peaks_out && sample_rate <= 0)
-    return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
-  if (batch == 0) return PDSP_OK;
-  if (!frames || (!amp_out && !peaks_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  if ((phase_out || peak_idx_out) && !amp_out) return fail(PDSP_ERR_BAD_ARG, "phase/peak index output needs amp_out");
-  DeviceGuard g(plan->device);
-  PDSP_HIP_TRY(g.err);
-  static_assert(sizeof(pdsp_peak32) == sizeof(pdsp::PeakRec), "peak record layout");
-  const long long n = plan->n;
-  const int bins = (int)(sides == PDSP_SIDES_ONE ? n / 2 + 1 : n);
-  const long long used = frame_len < n ? frame_len : n;
-  const float freq_scale = peaks_out ? (float)(sample_rate / (double)n) : 0.0f;
-  if (used == 0) {  // an empty frame is all zeros: amplitude 0, atan2(0, 0) = 0, peak 0
-    if (amp_out) PDSP_HIP_TRY(hipMemsetAsync(amp_out, 0, (size_t)batch * bins * sizeof(float), stream));
-    if (phase_out) PDSP_HIP_TRY(hipMemsetAsync(phase_out, 0, (size_t)batch * bins * sizeof(float), stream));
-    if (peak_idx_out) PDSP_HIP_TRY(hipMemsetAsync(peak_idx_out, 0, (size_t)batch * sizeof(int32_t), stream));
-    if (peaks_out) PDSP_HIP_TRY(hipMemsetAsync(peaks_out, 0, (size_t)batch * sizeof(pdsp_peak32), stream));
-    return PDSP_OK;
-  }
-  const float s_edge = 1.0f / (float)n, s_mid = (sides == PDSP_SIDES_ONE ? 2.0f : 1.0f) / (float)n;
-  if (plan->d_tw32_half && (window == nullptr || ((uintptr_t)window & 7) == 0)) {
-    // packed-real path: N/2-point complex transform + Hermitian split (+ findPeak) fused with the store.
-    // fast variant: whole 8-byte aligned frames, one-sided, no phase rows (config 4's shape)
-    const bool fast = ((uintptr_t)frames & 7) == 0 && (frame_stride & 1) == 0 && used == n &&
-                      sides == PDSP_SIDES_ONE && phase_out == nullptr;
-    PDSP_HIP_TRY(launch_packed(plan->log2n - 1, fast, frames, window, used, frame_stride, plan->d_tw32_half,
-                               plan->d_twr32, amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
-                               reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
-  } else {
-    // complex kernel on (x, 0) for N < 64 or an unaligned window; peaks come from the stored rows
-    float *amp = amp_out, *ph = phase_out;
-    const size_t row_bytes = (size_t)batch * bins * sizeof(float);
-    if (peaks_out && !amp) PDSP_HIP_TRY(hipMallocAsync((void **)&amp, row_bytes, stream));
-    if (peaks_out && !ph) PDSP_HIP_TRY(hipMallocAsync((void **)&ph, row_bytes, stream));
-    pdsp::StoreAmplitude<float> st{amp, ph, bins,
-                                   // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
-                                   (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1, s_edge, s_mid};
-    if (window) {
-      pdsp::LoadFrameWindowed<float, true> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, stream));
-    } else {
-      pdsp::LoadFrameWindowed<float, false> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft(plan->log2n, ld, st, plan->d_tw32, batch, stream));
-    }
-    if (peaks_out) {
-      hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<float>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph,
-                         bins, freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
-      PDSP_HIP_TRY(hipGetLastError());
-      if (!amp_out) PDSP_HIP_TRY(hipFreeAsync(amp, stream));
-      if (!phase_out) PDSP_HIP_TRY(hipFreeAsync(ph, stream));
-    }
-  }
-  if (peak_idx_out) {
-    hipLaunchKernelGGL((pdsp::find_peak_kernel<float>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
-                       peak_idx_out, batch);
-    PDSP_HIP_TRY(hipGetLastError());
-  }
-  return PDSP_OK;
-}
-
-int pdsp_spectrum_f32(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
-                      long long frame_stride, const float *window, int sides, float *amp_out, float *phase_out,
-                      int32_t *peak_out, pdsp_stream stream) {
-  if (batch > 0 && !amp_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  return spectrum_impl(plan, batch, frames, frame_len, frame_stride, window, sides, amp_out, phase_out, peak_out,
-                       nullptr, 1.0, (hipStream_t)stream);
-}
+/* ---- fused spectrum: peaks ---------------------------------------------------- */
 
 int pdsp_spectrum_peaks_f32(const pdsp_plan *plan, long long batch, const float *frames, long long frame_len,
                             long long frame_stride, const float *window, int sides, double sample_rate,
                             float *amp_out, float *phase_out, pdsp_peak32 *peaks_out, pdsp_stream stream) {
   if (batch > 0 && !peaks_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  return spectrum_impl(plan, batch, frames, frame_len, frame_stride, window, sides, amp_out, phase_out, nullptr,
-                       peaks_out, sample_rate, (hipStream_t)stream);
+  return spectrum_impl<float>(plan, batch, frames, frame_len, frame_stride, window, sides, amp_out, phase_out, nullptr,
+                              peaks_out, sample_rate, (hipStream_t)stream);
 }
 
 /* ---- host f64 drop-in entry points ------------------------------------------ */
@@ -671,25 +834,9 @@ int pdsp_fft_transform_host_f64(pdsp_plan *plan, long long batch, long long in_l
   std::lock_guard<std::mutex> lk(plan->mu);
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
-  const size_t cnt = (size_t)batch * (size_t)plan->n;
-  if (int rc = ensure_stage(plan, 4 * cnt)) return rc;
-  float *h_re = plan->h_stage, *h_im = h_re + cnt, *h_ore = h_im + cnt, *h_oim = h_ore + cnt;
-  float *d_re = plan->d_stage, *d_im = d_re + cnt, *d_ore = d_im + cnt, *d_oim = d_ore + cnt;
-  for (size_t i = 0; i < cnt; ++i) h_re[i] = (float)re_in[i];
-  if (im_in)
-    for (size_t i = 0; i < cnt; ++i) h_im[i] = (float)im_in[i];
-  hipStream_t s = plan->stream;
-  PDSP_HIP_TRY(hipMemcpyAsync(d_re, h_re, (im_in ? 2 : 1) * cnt * sizeof(float), hipMemcpyHostToDevice, s));
-  int rc;
-  if (inverse) rc = pdsp_fft_inverse_f32(plan, batch, d_re, d_im, d_ore, d_oim, s);
-  else if (im_in) rc = pdsp_fft_forward_complex_f32(plan, batch, d_re, d_im, d_ore, d_oim, s);
-  else rc = pdsp_fft_forward_real_f32(plan, batch, d_re, d_ore, d_oim, s);
-  if (rc) return rc;
-  PDSP_HIP_TRY(hipMemcpyAsync(h_ore, d_ore, 2 * cnt * sizeof(float), hipMemcpyDeviceToHost, s));
-  PDSP_HIP_TRY(hipStreamSynchronize(s));
-  for (size_t i = 0; i < cnt; ++i) re_out[i] = (double)h_ore[i];
-  for (size_t i = 0; i < cnt; ++i) im_out[i] = (double)h_oim[i];
-  return PDSP_OK;
+  if (host_precision() == 64 && plan->t64.tw)
+    return transform_host<double>(plan, batch, re_in, im_in, re_out, im_out, inverse);
+  return transform_host<float>(plan, batch, re_in, im_in, re_out, im_out, inverse);
 }
 
 int pdsp_apply_window_host_f64(const double *in, long long in_len, const double *window, long long window_len,
@@ -698,34 +845,16 @@ int pdsp_apply_window_host_f64(const double *in, long long in_len, const double 
   if (in_len == 0) return PDSP_OK;
   if (in_len < 0 || !in || !window || !out) return fail(PDSP_ERR_BAD_ARG, "bad applyWindow arguments");
   if (int rc = require_device()) return rc;
-  Scratch sc;
-  const size_t n = (size_t)in_len;
-  if (int rc = sc.reserve(3 * n)) return rc;
-  for (size_t i = 0; i < n; ++i) sc.h[i] = (float)in[i];
-  for (size_t i = 0; i < n; ++i) sc.h[n + i] = (float)window[i];
-  PDSP_HIP_TRY(hipMemcpy(sc.d, sc.h, 2 * n * sizeof(float), hipMemcpyHostToDevice));
-  if (int rc = pdsp_apply_window_f32(1, in_len, sc.d, sc.d + n, sc.d + 2 * n, nullptr)) return rc;
-  PDSP_HIP_TRY(hipMemcpy(sc.h, sc.d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) out[i] = (double)sc.h[i];
-  return PDSP_OK;
+  return host_precision() == 64 ? apply_window_host<double>(in, in_len, window, out)
+                                : apply_window_host<float>(in, in_len, window, out);
 }
 
-static int polar_host(const double *re, const double *im, long long n_, double *out, bool want_phase) {
-  if (n_ == 0) return PDSP_OK;
-  if (n_ < 0 || !re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "bad magnitude/phase arguments");
+static int polar_host(const double *re, const double *im, long long n, double *out, bool want_phase) {
+  if (n == 0) return PDSP_OK;
+  if (n < 0 || !re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "bad magnitude/phase arguments");
   if (int rc = require_device()) return rc;
-  Scratch sc;
-  const size_t n = (size_t)n_;
-  if (int rc = sc.reserve(3 * n)) return rc;
-  for (size_t i = 0; i < n; ++i) sc.h[i] = (float)re[i];
-  for (size_t i = 0; i < n; ++i) sc.h[n + i] = (float)im[i];
-  PDSP_HIP_TRY(hipMemcpy(sc.d, sc.h, 2 * n * sizeof(float), hipMemcpyHostToDevice));
-  const int rc = want_phase ? pdsp_phase_f32(n_, sc.d, sc.d + n, sc.d + 2 * n, nullptr)
-                            : pdsp_magnitude_f32(n_, sc.d, sc.d + n, sc.d + 2 * n, nullptr);
-  if (rc) return rc;
-  PDSP_HIP_TRY(hipMemcpy(sc.h, sc.d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) out[i] = (double)sc.h[i];
-  return PDSP_OK;
+  return host_precision() == 64 ? polar_host_t<double>(re, im, n, out, want_phase)
+                                : polar_host_t<float>(re, im, n, out, want_phase);
 }
 
 int pdsp_magnitude_host_f64(const double *re, const double *im, long long n, double *out) {
@@ -756,29 +885,14 @@ int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_r
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
   const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
-  const long long used = len < n ? len : n;
-  // staging: [frame n][amp bins][phase bins]
-  if (int rc = ensure_stage(plan, (size_t)(2 * n + 2 * bins))) return rc;
-  float *h = plan->h_stage, *d = plan->d_stage;
-  for (long long i = 0; i < used; ++i) h[i] = (float)samples[i];
-  for (long long i = used; i < n; ++i) h[i] = 0.0f;
-  const float *d_window = nullptr;
-  if (n != 1 && window != PDSP_WIN_RECT) {
-    if (int rc = plan_window(plan, window, &d_window)) return rc;
-  }
-  hipStream_t s = plan->stream;
-  PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
-  if (int rc = pdsp_spectrum_f32(plan, 1, d, n, n, d_window, sides, d + 2 * n, d + 2 * n + bins, nullptr, s))
+  const bool f64 = host_precision() == 64 && (plan->t64.tw_half || plan->t64.tw);
+  if (int rc = f64 ? spectrum_host_t<double>(plan, samples, len, window, sides, amp_out, phase_out)
+                   : spectrum_host_t<float>(plan, samples, len, window, sides, amp_out, phase_out))
     return rc;
-  PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * n, d + 2 * n, (size_t)(2 * bins) * sizeof(float), hipMemcpyDeviceToHost, s));
-  PDSP_HIP_TRY(hipStreamSynchronize(s));
-  for (long long i = 0; i < bins; ++i) amp_out[i] = (double)h[2 * n + i];
-  for (long long i = 0; i < bins; ++i) phase_out[i] = (double)h[2 * n + bins + i];
   if (int rc = pdsp_bin_frequencies(n, sample_rate, sides, freq_out, nullptr)) return rc;
   if (bins_out) *bins_out = bins;
   if (peak_out) {
-    // findPeak on the host over the f64-promoted amplitudes: exact strict-'>'
-    // and first-wins behaviour
+    // findPeak on the host over the f64 amplitudes: exact strict-'>' and first-wins behaviour
     const long long pk = pdsp_find_peak_f64(amp_out, bins);
     peak_out->index = (int32_t)pk;
     peak_out->frequency = freq_out[pk];

@@ -25,11 +25,11 @@ from .spectrum import SpectrumPeak, SpectrumResult
 
 
 class _Slot:
-    def __init__(self, frames: int, n: int, bins: int, device):
-        self.h_in = torch.empty((frames, n), dtype=torch.float32).pin_memory()
-        self.d_in = torch.empty((frames, n), dtype=torch.float32, device=device)
-        self.d_out = torch.empty((2, frames, bins), dtype=torch.float32, device=device)  # amp, phase
-        self.h_out = torch.empty((2, frames, bins), dtype=torch.float32).pin_memory()
+    def __init__(self, frames: int, n: int, bins: int, device, dtype):
+        self.h_in = torch.empty((frames, n), dtype=dtype).pin_memory()
+        self.d_in = torch.empty((frames, n), dtype=dtype, device=device)
+        self.d_out = torch.empty((2, frames, bins), dtype=dtype, device=device)  # amp, phase
+        self.h_out = torch.empty((2, frames, bins), dtype=dtype).pin_memory()
         self.done = torch.cuda.Event()
         self.count = 0
         self.in_flight = False
@@ -54,6 +54,8 @@ class SpectrumStream:
         if not torch.cuda.is_available():
             raise PdspError(_capi.ERR_DEVICE, "no HIP device available (the pdsp engine has no CPU fallback)")
         self.batch_frames = int(batch_frames)
+        # same arithmetic as spectrum(): the host precision (pdsp_set_host_precision), f64 by default
+        self.dtype = torch.float64 if lib.pdsp_set_host_precision(0) == 64 else torch.float32
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._plans: dict[int, BatchedFft] = {}     # Map<size, FFT>
         self._freqs: dict[int, np.ndarray] = {}
@@ -81,7 +83,7 @@ class SpectrumStream:
             if not s.in_flight and s.count == 0:
                 return s, ready
         if len(slots) < 2:
-            s = _Slot(self.batch_frames, n, self._bins(n), self.device)
+            s = _Slot(self.batch_frames, n, self._bins(n), self.device, self.dtype)
             slots.append(s)
             return s, ready
         ready = self._harvest_oldest()  # both busy: wait for the older one
@@ -93,7 +95,7 @@ class SpectrumStream:
             return
         plan = self._plans.get(n)
         if plan is None:
-            plan = self._plans[n] = BatchedFft(n, self.device)
+            plan = self._plans[n] = BatchedFft(n, self.device, dtype=self.dtype)
         win = None if (self.window == "rect" or n == 1) else plan.window(self.window)
         cnt, bins = s.count, self._bins(n)
         with torch.cuda.stream(self._copy):
@@ -102,7 +104,7 @@ class SpectrumStream:
             uploaded.record(self._copy)
         self._compute.wait_event(uploaded)
         with torch.cuda.stream(self._compute):
-            check(lib.pdsp_spectrum_f32(plan._h, cnt, _ptr(s.d_in), n, n, _ptr(win), 0 if self.sides == "one" else 1,
+            check(getattr(lib, "pdsp_spectrum_" + plan._sfx)(plan._h, cnt, _ptr(s.d_in), n, n, _ptr(win), 0 if self.sides == "one" else 1,
                                         _ptr(s.d_out[0]), _ptr(s.d_out[1]), None, _stream_ptr(self.device)))
             s.h_out[:, :cnt].copy_(s.d_out[:, :cnt], non_blocking=True)
             s.done.record(self._compute)

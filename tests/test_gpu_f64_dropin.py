@@ -1,0 +1,131 @@
+"""The host drop-in in its default f64 mode, held to the REFERENCE'S OWN tolerances
+(test/reallife/signals.test.ts, edge_cases.test.ts, phase.test.ts, test/fft.test.ts,
+test/window.test.ts): 1e-10 absolute against the NumPy goldens, not just the f32 contract.
+Also the f32 mode (north-star contract) and the f64 device-pointer family."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def wrap(d):
+    return np.abs((d + np.pi) % (2 * np.pi) - np.pi)
+
+
+@pytest.fixture
+def f64_mode(pdsp):
+    prev = pdsp.lib.pdsp_set_host_precision(64)
+    yield
+    pdsp.lib.pdsp_set_host_precision(prev)
+
+
+def test_reference_signal_tests_pass_verbatim(pdsp, f64_mode, reallife, manifest):
+    fft = pdsp.FFT(1024)
+    for c in manifest["reallife"]:
+        name = c["name"]
+        x = reallife[name + "/signal"]
+        out = fft.forward(x)
+        gre, gim = reallife[name + "/fftRe"], reallife[name + "/fftIm"]
+        gmag, gph = np.sqrt(gre ** 2 + gim ** 2), np.arctan2(gim, gre)
+        if name == "large_amplitude":      # edge_cases.test.ts:166-175
+            assert max(np.abs(out.real - gre).max(), np.abs(out.imag - gim).max()) / np.abs(gre + 1j * gim).max() < 1e-9
+            continue
+        if name == "tiny_amplitude":       # edge_cases.test.ts:145-146
+            assert max(np.abs(out.real - gre).max(), np.abs(out.imag - gim).max()) < 1e-20
+            continue
+        assert np.abs(out.real - gre).max() < 1e-10, name          # signals.test.ts:22-23
+        assert np.abs(out.imag - gim).max() < 1e-10, name
+        assert np.abs(pdsp.magnitude(out) - gmag).max() < 1e-10, name      # :31
+        mask = gmag > 1e-6                                                  # :41-47
+        assert wrap(pdsp.phase(out)[mask] - gph[mask]).max(initial=0) < 1e-10, name
+        back = fft.inverse(out)                                             # :56-62
+        assert np.abs(back.real - x).max() < 1e-10 and np.abs(back.imag).max() < 1e-10
+    z = fft.forward(reallife["zeros/signal"])
+    assert not z.real.any() and not z.imag.any()                            # toBe(0)
+    d = fft.forward(reallife["dc_level1/signal"])
+    assert abs(d.real[0] - 1024) < 1e-10 and np.abs(d.real[1:]).max() < 1e-10
+
+
+def test_reference_fixture_tests_pass_verbatim(pdsp, f64_mode, v01, manifest):
+    for c in manifest["v01_cases"]:                                         # test/fft.test.ts:20-41 (1e-6)
+        x = v01[f"case/{c['name']}/input"]
+        fft = pdsp.FFT(c["n"])
+        out = fft.forward(x)
+        assert np.abs(out.real - v01[f"case/{c['name']}/fftRe"]).max() < 1e-6
+        assert np.abs(out.imag - v01[f"case/{c['name']}/fftIm"]).max() < 1e-6
+        assert np.abs(out.real - v01[f"case/{c['name']}/fftRe"]).max() < 1e-11 * c["n"]   # and far tighter
+        back = fft.inverse(out)
+        assert np.abs(back.real - x).max() < 1e-6
+    (c,) = [c for c in manifest["v01_cases"] if c["kind"] == "sine_bin_centered"]       # test/spectrum.test.ts
+    r = pdsp.spectrum(v01[f"case/{c['name']}/input"], {"sampleRate": c["sampleRate"], "fftSize": c["n"]})
+    assert r.peak.index == 32 and abs(r.peak.frequency - 1500) <= 1e-6 and abs(r.peak.amplitude - 0.8) <= 1e-3
+    assert abs(r.peak.amplitude - 0.8) < 1e-12 and abs(r.peak.phase + np.pi / 2) < 1e-9
+
+
+def test_spectrum_matches_oracle_to_f64_rounding(pdsp, f64_mode, oracle_mod, reallife):
+    rng = np.random.default_rng(8)
+    for n_in, opts in [(1000, {"sampleRate": 48000, "window": "hann"}), (64, {}), (5000, {"sides": "two", "window": "blackman"}),
+                       (16384, {"window": "hamming"}), (3, {}), (1, {})]:
+        x = rng.standard_normal(n_in)
+        g = pdsp.spectrum(x, opts)
+        w = oracle_mod.spectrum(x, sample_rate=opts.get("sampleRate", 1), window=opts.get("window", "rect"),
+                                sides=opts.get("sides", "one"))
+        assert np.abs(g.amplitude - w["amplitude"]).max() <= 1e-13 * max(1.0, w["amplitude"].max())
+        assert np.array_equal(g.frequencies, w["frequencies"])
+        assert g.peak.index == w["peak"]["index"] or abs(w["amplitude"][g.peak.index] - w["peak"]["amplitude"]) < 1e-13
+    # phase.test.ts: cosine leads sine by pi/2 at bin 8; DC phase 0 / pi
+    s = pdsp.spectrum(reallife["sine_bin8_amp1.0/signal"], {"fftSize": 1024})
+    c = pdsp.spectrum(reallife["cosine_bin8/signal"], {"fftSize": 1024})
+    assert abs((c.phase[8] - s.phase[8]) - np.pi / 2) < 1e-6
+    assert pdsp.phase(pdsp.FFT(64).forward(np.ones(64)))[0] == 0
+    assert abs(abs(pdsp.phase(pdsp.FFT(64).forward(-np.ones(64)))[0]) - np.pi) < 1e-15
+
+
+def test_f32_mode_is_the_north_star_contract(pdsp, reallife):
+    prev = pdsp.lib.pdsp_set_host_precision(32)
+    try:
+        out = pdsp.FFT(1024).forward(reallife["sine_440hz/signal"])
+        want = reallife["sine_440hz/fftRe"] + 1j * reallife["sine_440hz/fftIm"]
+        err = rel_err(out.real + 1j * out.imag, want)
+        assert 1e-9 < err <= 1e-5      # f32 arithmetic, inside the stated tolerance
+    finally:
+        pdsp.lib.pdsp_set_host_precision(prev)
+    big = pdsp.FFT(16384).forward(np.ones(16384))   # beyond the f64 single-pass limit: computed in f32
+    assert abs(big.real[0] - 16384) < 1e-2 and np.abs(big.real[1:]).max() == 0
+
+
+@pytest.mark.parametrize("log2n", [0, 2, 5, 8, 10, 12, 13])
+def test_f64_device_family(oracle_mod, log2n):
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n)
+    re, im = rng.standard_normal((6, n)), rng.standard_normal((6, n))
+    plan = BatchedFft(n, "cuda:0", dtype=torch.float64)
+    ore, oim = plan.forward(torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda())
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    assert rel_err(ore.cpu().numpy() + 1j * oim.cpu().numpy(), wre + 1j * wim) <= 1e-14
+    bre, bim = plan.inverse(ore, oim)
+    assert rel_err(bre.cpu().numpy(), re) <= 1e-14
+    rre, rim = plan.forward(torch.from_numpy(re).cuda())
+    wre, wim = oracle_mod.Plan(n).forward(re)
+    assert rel_err(rre.cpu().numpy() + 1j * rim.cpu().numpy(), wre + 1j * wim) <= 1e-14
+    amp, ph, pk = plan.spectrum(torch.from_numpy(re).cuda(), "hann", "one", want_phase=True, want_peak=True)
+    win = oracle_mod.create_window("hann", n) if n > 1 else None
+    wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(re, window=win, want_phase=True, want_peak=True)
+    assert rel_err(amp.cpu().numpy(), wamp) <= 1e-14
+
+
+def test_f64_limits(pdsp):
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    plan = BatchedFft(16384, "cuda:0", dtype=torch.float64)
+    x = torch.randn((2, 16384), device="cuda", dtype=torch.float64)
+    with pytest.raises(pdsp.PdspError, match="single-pass limit"):
+        plan.forward(x)                       # complex f64 stops at 8192
+    amp, _, _ = plan.spectrum(x, "rect", "one")  # the real spectrum (an 8192-point transform) still fits
+    energy = (amp[:, 0] ** 2 + amp[:, -1] ** 2 + 0.5 * (amp[:, 1:-1] ** 2).sum(dim=1)) * 16384
+    assert float(((energy - (x ** 2).sum(dim=1)).abs() / (x ** 2).sum(dim=1)).max()) < 1e-13
+    assert pdsp.lib.pdsp_max_size(8) == 8192 and pdsp.lib.pdsp_max_size(4) == 16384
