@@ -161,16 +161,23 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ramp-seconds", type=float, default=0.6, help="untimed clock-ramp before the warm-up steps")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (1-GPU rehearsal)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of the output slabs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the pdsp engine has no CPU fallback)", file=sys.stderr)
         return 2
@@ -247,7 +254,10 @@ def main() -> int:
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local])
+            if args.dist_backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     # Untimed clock ramp: a cold MI355X needs ~0.5 s of work before its clocks settle
@@ -316,7 +326,9 @@ def main() -> int:
                        "n": n, "batch_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "parallelism": f"batch-shard x{world}", "launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profile(kernel_name),
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         # PMC bytes of the committed rocprofv3 passes: only valid for the profiled shape
+                         "traffic": traffic_from_profile(kernel_name) if args.batch is None and args.chunk == 16384 else None,
                          "kernel": kernel_label,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launch_ms_avg": launch_ms, "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
