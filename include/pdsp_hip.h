@@ -51,7 +51,7 @@ typedef enum pdsp_status {
   PDSP_ERR_WINDOW_TYPE = 5,     /* "Unsupported window type: ${t}"                fourier.ts:47-50 */
   PDSP_ERR_FFT_SIZE = 6,        /* "FFT size must be positive, got ${size}"       fourier.ts:152-154 */
   PDSP_ERR_SAMPLE_RATE = 7,     /* "Sample rate must be positive, got ${sr}"      fourier.ts:155-157 */
-  PDSP_ERR_UNSUPPORTED_SIZE = 8,/* power of two, but beyond what the single-pass LDS kernel holds */
+  PDSP_ERR_UNSUPPORTED_SIZE = 8,/* power of two, but beyond pdsp_max_size() for that precision */
   PDSP_ERR_BAD_ARG = 9,         /* null pointer / negative batch */
   PDSP_ERR_DEVICE = 10          /* no GPU, or a HIP runtime error (message has the HIP text) */
 } pdsp_status;
@@ -88,14 +88,14 @@ PDSP_API int pdsp_version(void);
 PDSP_API const char *pdsp_last_error(void);
 /* Number of visible HIP devices (0 when there is none); never fails. */
 PDSP_API int pdsp_device_count(void);
-/* Largest N the single-pass complex kernels take for 4-byte / 8-byte scalars (16384 / 8192;
- * the real-frame spectrum path runs an N/2-point transform, so it takes N up to 16384 in f64). */
+/* Largest N for 4-byte / 8-byte scalars: 2^18 / 2^17.  Up to 16384 / 8192 (16384 for the f64
+ * real-frame spectrum) one LDS-resident pass; above, a three-pass four-step transform. */
 PDSP_API int pdsp_max_size(int scalar_bytes);
 
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).
- *   64 (default): f64 on the device wherever the single-pass kernels hold the size -- the drop-in
- *       then meets the reference's own test tolerances (1e-10 against NumPy, signals.test.ts:22-23),
- *       not just the f32 contract; sizes beyond (complex N = 16384) compute in f32.
+ *   64 (default): f64 on the device for every size up to 2^17 -- the drop-in then meets the
+ *       reference's own test tolerances (1e-10 against NumPy, signals.test.ts:22-23), not just the
+ *       f32 contract; N = 2^18 computes in f32.
  *   32: always f32 (the north-star's stated contract, max|err|/max|X| <= 1e-5).
  * PDSP_HOST_PRECISION=32 in the environment presets it. */
 PDSP_API int pdsp_set_host_precision(int bits);
@@ -214,8 +214,8 @@ PDSP_API int pdsp_spectrum_peaks_f32(const pdsp_plan *plan, long long batch,
                                      pdsp_stream stream);
 
 /* ---- the same device-pointer family in f64 ------------------------------ */
-/* Identical contracts with double rows.  Complex transforms: N <= 8192; pdsp_spectrum_f64:
- * N <= 16384 (PDSP_ERR_UNSUPPORTED_SIZE beyond).  ~1e-15 relative to max vs the f64 reference. */
+/* Identical contracts with double rows, N <= 2^17 (PDSP_ERR_UNSUPPORTED_SIZE beyond).
+ * ~1e-15 relative to max vs the f64 reference. */
 PDSP_API int pdsp_fft_forward_real_f64(const pdsp_plan *plan, long long batch,
                                        const double *re_in, double *re_out, double *im_out,
                                        pdsp_stream stream);

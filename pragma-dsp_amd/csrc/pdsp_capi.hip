@@ -75,7 +75,16 @@ struct Tables {
   T2 *tw_half = nullptr;
   T2 *twr = nullptr;
   T *win[4] = {nullptr, nullptr, nullptr, nullptr};  // createWindow(type, N), built on first use
+  // four-step path (N beyond the single-pass limit): `tw` then belongs to the N2-point rows,
+  // N1 = N / N2, and W_N^m = twa[m >> 9] * twb[m & 511]
+  int log2n2 = 0;  // log2 of the transform `tw` serves (== log2 N when single-pass)
+  int log2n1 = 0;
+  T2 *twa = nullptr;
+  T2 *twb = nullptr;
   void release() {
+    if (twa) (void)hipFree(twa);
+    if (twb) (void)hipFree(twb);
+    twa = twb = nullptr;
     if (tw) (void)hipFree(tw);
     if (tw_half) (void)hipFree(tw_half);
     if (twr) (void)hipFree(twr);
@@ -216,6 +225,66 @@ int check_plan_batch(const pdsp_plan *plan, long long batch) {
   return PDSP_OK;
 }
 
+// Four-step transform of `batch` rows of N = N1*N2 points into scratch planes (pass A + B);
+// the caller runs pass C.  REAL rows may carry a window and be shorter than N.
+template <typename T>
+int fourstep_ab(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, const T *win,
+                long long in_stride, long long frame_len, T *s_re, T *s_im, hipStream_t s) {
+  using T2 = typename pdsp::vec2<T>::type;
+  const Tables<T> &t = tables<T>(plan);
+  const int n2 = 1 << t.log2n2;
+  const long long blocks = batch * (n2 / 256);
+  if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
+  const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
+  const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
+#define PDSP_COLS(L, R, W)                                                                                        \
+  hipLaunchKernelGGL((pdsp::fourstep_cols_kernel<T, L, R, W>), dim3((unsigned)blocks), dim3(256), 0, s, re_in, im_in, \
+                     win, s_re, s_im, twa, twb, n2, in_stride, frame_len, batch)
+#define PDSP_COLS_L(L)                     \
+  do {                                     \
+    if (im_in) PDSP_COLS(L, false, false); \
+    else if (win) PDSP_COLS(L, true, true); \
+    else PDSP_COLS(L, true, false);        \
+  } while (0)
+  switch (t.log2n1) {
+    case 1: PDSP_COLS_L(1); break;
+    case 2: PDSP_COLS_L(2); break;
+    case 3: PDSP_COLS_L(3); break;
+    case 4: PDSP_COLS_L(4); break;
+    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported four-step split");
+  }
+#undef PDSP_COLS_L
+#undef PDSP_COLS
+  PDSP_HIP_TRY(hipGetLastError());
+  // pass B: the N1 * batch rows of N2 points, in place (each workgroup loads its row before it stores)
+  pdsp::LoadComplex<T> ld{s_re, s_im, n2};
+  pdsp::StoreComplex<T> st{s_re, s_im, n2, T(1)};
+  PDSP_HIP_TRY(launch_fft<T>(t.log2n2, ld, st, t.tw, batch << t.log2n1, s));
+  (void)sizeof(T2);
+  return PDSP_OK;
+}
+
+template <typename T, int MODE>
+int fourstep_c(const pdsp_plan *plan, long long batch, const T *s_re, const T *s_im, T *o1, T *o2, T scale, int bins,
+               int nyq, T s_edge, T s_mid, hipStream_t s) {
+  const Tables<T> &t = tables<T>(plan);
+  const int n2 = 1 << t.log2n2;
+  const long long blocks = batch * (n2 / 256);
+#define PDSP_OUT(L)                                                                                              \
+  hipLaunchKernelGGL((pdsp::fourstep_out_kernel<T, L, MODE>), dim3((unsigned)blocks), dim3(256), 0, s, s_re, s_im, o1, \
+                     o2, n2, scale, bins, nyq, s_edge, s_mid, batch)
+  switch (t.log2n1) {
+    case 1: PDSP_OUT(1); break;
+    case 2: PDSP_OUT(2); break;
+    case 3: PDSP_OUT(3); break;
+    case 4: PDSP_OUT(4); break;
+    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported four-step split");
+  }
+#undef PDSP_OUT
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
 template <typename T>
 int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out, T scale,
                 hipStream_t s) {
@@ -228,6 +297,15 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
                 (int)(8 * sizeof(T)), 1 << max_log2n<T>());
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
+  if (t.log2n1 > 0) {  // beyond the single-pass limit: four-step through stream-ordered scratch planes
+    T *scratch = nullptr;
+    const size_t plane = (size_t)batch * (size_t)plan->n;
+    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, 2 * plane * sizeof(T), s));
+    int rc = fourstep_ab<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, scratch, scratch + plane, s);
+    if (!rc) rc = fourstep_c<T, 0>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
+    (void)hipFreeAsync(scratch, s);
+    return rc;
+  }
   hipError_t e;
   pdsp::StoreComplex<T> st{re_out, im_out, plan->n, scale};
   if (im_in) {
@@ -353,9 +431,28 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
   using T2 = typename pdsp::vec2<T>::type;
   hipError_t e = hipSuccess;
   if (full) {
-    const std::vector<T2> tw = build_twiddles<T2>(log2n);
+    t.log2n2 = log2n > max_log2n<T>() ? max_log2n<T>() : log2n;
+    t.log2n1 = log2n - t.log2n2;
+    const std::vector<T2> tw = build_twiddles<T2>(t.log2n2);
     e = hipMalloc((void **)&t.tw, tw.size() * sizeof(T2));
     if (e == hipSuccess) e = hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(T2), hipMemcpyHostToDevice);
+    if (e == hipSuccess && t.log2n1 > 0) {  // W_N^m = twa[m >> 9] * twb[m & 511]
+      std::vector<T2> a((size_t)(size >> 9)), b(512);
+      for (size_t i = 0; i < a.size(); ++i) {
+        const double angle = (-2.0 * M_PI * (double)(i << 9)) / (double)size;
+        a[i].x = (T)std::cos(angle);
+        a[i].y = (T)std::sin(angle);
+      }
+      for (size_t i = 0; i < 512; ++i) {
+        const double angle = (-2.0 * M_PI * (double)i) / (double)size;
+        b[i].x = (T)std::cos(angle);
+        b[i].y = (T)std::sin(angle);
+      }
+      e = hipMalloc((void **)&t.twa, a.size() * sizeof(T2));
+      if (e == hipSuccess) e = hipMemcpy(t.twa, a.data(), a.size() * sizeof(T2), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc((void **)&t.twb, b.size() * sizeof(T2));
+      if (e == hipSuccess) e = hipMemcpy(t.twb, b.data(), b.size() * sizeof(T2), hipMemcpyHostToDevice);
+    }
   }
   if (e == hipSuccess && half) {
     const std::vector<T2> twh = build_twiddles<T2>(log2n - 1);
@@ -432,6 +529,30 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     return PDSP_OK;
   }
   const T s_edge = T(1) / (T)n, s_mid = (sides == PDSP_SIDES_ONE ? T(2) : T(1)) / (T)n;
+  if (t.log2n1 > 0) {  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in pass C
+    T *scratch = nullptr, *amp = amp_out, *ph = phase_out;
+    const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins;
+    const size_t extra = (peaks_out && !amp ? rows : 0) + (peaks_out && !ph ? rows : 0);
+    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, (2 * plane + extra) * sizeof(T), stream));
+    if (peaks_out && !amp) amp = scratch + 2 * plane;
+    if (peaks_out && !ph) ph = scratch + 2 * plane + (amp_out ? 0 : rows);
+    int rc = fourstep_ab<T>(plan, batch, frames, nullptr, window, frame_stride, used, scratch, scratch + plane, stream);
+    if (!rc)
+      rc = fourstep_c<T, 1>(plan, batch, scratch, scratch + plane, amp, ph, T(1), bins,
+                            (sides == PDSP_SIDES_ONE) ? (int)(n / 2) : -1, s_edge, s_mid, stream);
+    if (!rc && peaks_out) {
+      hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph, bins,
+                         freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
+      if (hipGetLastError() != hipSuccess) rc = fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
+    }
+    if (!rc && peak_idx_out) {
+      hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
+                         peak_idx_out, batch);
+      if (hipGetLastError() != hipSuccess) rc = fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
+    }
+    (void)hipFreeAsync(scratch, stream);
+    return rc;
+  }
   constexpr uintptr_t kPairMask = 2 * sizeof(T) - 1;  // alignment of one (re, im) pair
   if (t.tw_half && (window == nullptr || ((uintptr_t)window & kPairMask) == 0)) {
     // packed-real path: N/2-point complex transform + Hermitian split (+ findPeak) fused with the store.
@@ -594,9 +715,9 @@ int pdsp_device_count(void) {
   return count;
 }
 
-int pdsp_max_size(int scalar_bytes) {
-  if (scalar_bytes == 4) return 1 << pdsp::kMaxLog2N_f32;
-  if (scalar_bytes == 8) return 1 << pdsp::kMaxLog2N_f64;
+int pdsp_max_size(int scalar_bytes) {  // incl. the four-step path
+  if (scalar_bytes == 4) return 1 << (pdsp::kMaxLog2N_f32 + pdsp::kMaxLog2N1);
+  if (scalar_bytes == 8) return 1 << (pdsp::kMaxLog2N_f64 + pdsp::kMaxLog2N1);
   return 0;
 }
 
@@ -684,9 +805,9 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
   *plan_out = nullptr;
   if (!pdsp_is_pow2(size)) return fail(PDSP_ERR_SIZE_NOT_POW2, "FFT size must be power of two, got %lld", size);
   const int log2n = ilog2ll(size);
-  if (log2n > pdsp::kMaxLog2N_f32)
-    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the single-pass limit %d", size,
-                1 << pdsp::kMaxLog2N_f32);
+  if (log2n > pdsp::kMaxLog2N_f32 + pdsp::kMaxLog2N1)
+    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the supported maximum %d", size,
+                1 << (pdsp::kMaxLog2N_f32 + pdsp::kMaxLog2N1));
   if (int rc = require_device()) return rc;
   int count = 0;
   PDSP_HIP_TRY(hipGetDeviceCount(&count));
@@ -699,11 +820,13 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
   p->n = size;
   p->log2n = log2n;
   p->device = device;
-  hipError_t e = upload_tables<float>(p->t32, log2n, size, true, log2n >= 6);
-  // f64 tables wherever the f64 single-pass kernels hold the size: the complex transform up to
-  // 2^13 (LDS), the packed-real spectrum (an N/2-point transform) up to N = 2^14
+  // f32: single-pass up to 2^14, four-step (N1 <= 16 columns x 2^14-point rows) up to 2^18; the
+  // packed-real spectrum tables exist for the single-pass sizes
+  hipError_t e = upload_tables<float>(p->t32, log2n, size, true, log2n >= 6 && log2n <= pdsp::kMaxLog2N_f32);
+  // f64: the complex transform single-pass up to 2^13 and four-step up to 2^17; the packed-real
+  // spectrum (an N/2-point transform) up to N = 2^14
   if (e == hipSuccess)
-    e = upload_tables<double>(p->t64, log2n, size, log2n <= pdsp::kMaxLog2N_f64,
+    e = upload_tables<double>(p->t64, log2n, size, log2n <= pdsp::kMaxLog2N_f64 + pdsp::kMaxLog2N1,
                               log2n >= 6 && log2n - 1 <= pdsp::kMaxLog2N_f64);
   if (e != hipSuccess) {
     p->t32.release();

@@ -542,6 +542,92 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   }
 }
 
+// ---- four-step path for N beyond the single-pass LDS limit --------------------
+// N = N1 * N2 with N2 = the largest single-pass size and 2 <= N1 <= 16.  Input index
+// n = n1*N2 + n2, output index k = k1 + N1*k2.
+//   A  (this kernel)  for every column n2: the N1-point DFT over n1 (stride N2), times
+//      W_N^{n2*k1}, written back in the same [k1][n2] layout.  One thread per column, so
+//      both its loads and stores are unit-stride across the lanes.
+//   B  fft_stockham_kernel on the N1 rows of N2 points, in place.
+//   C  (fourstep_out_kernel) transposes [k1][k2] -> k1 + N1*k2 with the 1/N of the inverse,
+//      or reduces to amplitude / phase rows for the spectrum path.
+// W_N^m = twa[m >> 9] * twb[m & 511]: two small host-built f64 tables, one product.
+template <typename T, int LOG2N1, bool REAL_IN, bool HAS_WIN>
+__global__ void __launch_bounds__(256)
+fourstep_cols_kernel(const T *__restrict__ re, const T *__restrict__ im, const T *__restrict__ win,
+                     T *__restrict__ sre, T *__restrict__ sim, const cx<T> *__restrict__ twa,
+                     const cx<T> *__restrict__ twb, int n2, long long in_stride, long long frame_len,
+                     long long batch) {
+  constexpr int N1 = 1 << LOG2N1;
+  const int cblocks = n2 / 256;
+  const long long b = blockIdx.x / cblocks;
+  const int col = (int)(blockIdx.x % cblocks) * 256 + (int)threadIdx.x;
+  if (b >= batch) return;
+  const size_t n = (size_t)N1 * (size_t)n2;
+  const T *const xr = re + (size_t)b * (size_t)in_stride;
+  const T *const xi = REAL_IN ? nullptr : im + (size_t)b * (size_t)in_stride;
+  const long long last = frame_len - 1;  // REAL_IN rows may be shorter than N (buildFrame zero-padding)
+  cx<T> a[N1];
+  static_for<N1>([&](auto q) {
+    const long long i = (long long)q * n2 + col;
+    if constexpr (REAL_IN) {
+      T v = ld_stream(xr + (size_t)(i < last ? i : last));
+      v = i <= last ? v : T(0);
+      if constexpr (HAS_WIN) v *= win[i];
+      a[q] = cx<T>{v, T(0)};
+    } else {
+      a[q] = cx<T>{ld_stream(xr + (size_t)i), ld_stream(xi + (size_t)i)};
+    }
+  });
+  fft_reg<T, N1>(a);
+  T *const orow = sre + (size_t)b * n, *const irow = sim + (size_t)b * n;
+  static_for<N1>([&](auto k1) {
+    cx<T> v = a[bitrev(k1, LOG2N1)];
+    if constexpr (k1 > 0) {
+      const unsigned m = (unsigned)col * (unsigned)k1;  // < N <= 2^18
+      v = cmul(v, cmul(twa[m >> 9], twb[m & 511]));
+    }
+    orow[(size_t)k1 * n2 + col] = v.x;
+    irow[(size_t)k1 * n2 + col] = v.y;
+  });
+}
+
+// Pass C.  MODE 0: complex planes out (times `scale`); MODE 1: amplitude (+ phase) rows of
+// spectrum(), bins = N/2+1 or N.  One thread per k2, N1 consecutive outputs each.
+template <typename T, int LOG2N1, int MODE>
+__global__ void __launch_bounds__(256)
+fourstep_out_kernel(const T *__restrict__ sre, const T *__restrict__ sim, T *__restrict__ ore, T *__restrict__ oim,
+                    int n2, T scale, int bins, int nyq, T s_edge, T s_mid, long long batch) {
+  constexpr int N1 = 1 << LOG2N1;
+  const int cblocks = n2 / 256;
+  const long long b = blockIdx.x / cblocks;
+  const int k2 = (int)(blockIdx.x % cblocks) * 256 + (int)threadIdx.x;
+  if (b >= batch) return;
+  const size_t n = (size_t)N1 * (size_t)n2;
+  const T *const rr = sre + (size_t)b * n, *const ri = sim + (size_t)b * n;
+  T vr[N1], vi[N1];
+  static_for<N1>([&](auto k1) {
+    vr[k1] = rr[(size_t)k1 * n2 + k2];
+    vi[k1] = ri[(size_t)k1 * n2 + k2];
+  });
+  if constexpr (MODE == 0) {
+    T *const o1 = ore + (size_t)b * n + (size_t)k2 * N1, *const o2 = oim + (size_t)b * n + (size_t)k2 * N1;
+    static_for<N1>([&](auto k1) {
+      o1[k1] = vr[k1] * scale;
+      o2[k1] = vi[k1] * scale;
+    });
+  } else {
+    T *const arow = ore + (size_t)b * (size_t)bins, *const prow = oim ? oim + (size_t)b * (size_t)bins : nullptr;
+    static_for<N1>([&](auto k1) {
+      const int k = k2 * N1 + k1;
+      if (k < bins) {
+        arow[k] = mag(cx<T>{vr[k1], vi[k1]}) * ((k == 0 || k == nyq) ? s_edge : s_mid);
+        if (prow) prow[k] = T(atan2(vi[k1], vr[k1]));
+      }
+    });
+  }
+}
+
 // ---- element-wise kernels (stand-alone applyWindow / magnitude / phase) -----
 
 template <typename T>

@@ -14,6 +14,7 @@ namespace pdsp {
 constexpr int kMaxPasses = 4;
 constexpr int kMaxLog2N_f32 = 14;  // (N + N/16) * 8 B of LDS <= 160 KiB
 constexpr int kMaxLog2N_f64 = 13;  // (N + N/16) * 16 B
+constexpr int kMaxLog2N1 = 4;      // four-step path: N = N1 * N2, N1 <= 16 columns per thread
 
 struct RadixPlan {
   int log2n;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pdsp):
     # and the ctypes binding covers all of them
     assert set(syms) == set(pdsp.lib._pdsp_symbols)
     assert pdsp.lib.pdsp_version() >= 100
-    assert pdsp.lib.pdsp_max_size(4) == 16384
+    assert pdsp.lib.pdsp_max_size(4) == 262144 and pdsp.lib.pdsp_max_size(8) == 131072
 
 
 def test_product_does_not_touch_the_oracle():
