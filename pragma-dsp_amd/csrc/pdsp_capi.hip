@@ -125,8 +125,8 @@ namespace {
 // (src/core/fft.ts:45-61 builds cos/sin of (-2*pi*k)/m per stage with Math.cos /
 // Math.sin; same direct evaluation here, no recurrence), then rounded once.
 template <typename T2>
-std::vector<T2> build_twiddles(int log2n) {
-  const pdsp::RadixPlan p = pdsp::make_radix_plan(log2n);
+std::vector<T2> build_twiddles(int log2n, int log2e = 4) {
+  const pdsp::RadixPlan p = pdsp::make_radix_plan(log2n, log2e);
   std::vector<T2> tw((size_t)(p.twcount > 0 ? p.twcount : 1));
   for (int i = 0; i < p.np; ++i) {
     const int ns = p.ns[i], r = p.r[i];
@@ -178,7 +178,7 @@ hipError_t launch_packed_one(bool fast, const T *frames, const T *win, long long
                              const typename pdsp::vec2<T>::type *tw, const typename pdsp::vec2<T>::type *twr, T *amp,
                              T *ph, int two_sided, T s_edge, T s_mid, pdsp::PeakRec *peaks, T freq_scale,
                              long long batch, hipStream_t s) {
-  using TR = pdsp::FftTraits<LOG2M>;
+  using TR = pdsp::FftTraits<LOG2M, pdsp::packed_log2e(LOG2M)>;
   const long long ngroups = (batch + TR::ROWS - 1) / TR::ROWS;
   const dim3 block(TR::WG);
 #define PDSP_LAUNCH(F, W, P)                                                                                  \
@@ -455,7 +455,7 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
     }
   }
   if (e == hipSuccess && half) {
-    const std::vector<T2> twh = build_twiddles<T2>(log2n - 1);
+    const std::vector<T2> twh = build_twiddles<T2>(log2n - 1, pdsp::packed_log2e(log2n - 1));
     std::vector<T2> twr((size_t)(size / 4 + 1));
     for (long long k = 0; k <= size / 4; ++k) {
       const double angle = (-2.0 * M_PI * (double)k) / (double)size;

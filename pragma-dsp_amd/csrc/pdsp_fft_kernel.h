@@ -34,6 +34,24 @@
 
 namespace pdsp {
 
+// Diagnostic build only (tools/kbench -DPDSP_STAMPS): wave 0 of each workgroup adds the shader
+// cycles between phase boundaries into pdsp_stamp_acc[slot]; nothing is emitted otherwise.
+#ifdef PDSP_STAMPS
+__device__ unsigned long long pdsp_stamp_acc[64];
+#define PDSP_STAMP_INIT() unsigned long long stamp_last_ = clock64()
+#define PDSP_STAMP(slot)                                                          \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    const unsigned long long t_ = clock64();                                      \
+    if (threadIdx.x == 0) atomicAdd(&pdsp_stamp_acc[slot], t_ - stamp_last_);     \
+    stamp_last_ = clock64();                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  } while (0)
+#else
+#define PDSP_STAMP_INIT() ((void)0)
+#define PDSP_STAMP(slot) ((void)0)
+#endif
+
 template <typename T> struct vec2;
 template <> struct vec2<float> { using type = float2; };
 template <> struct vec2<double> { using type = double2; };
@@ -66,6 +84,16 @@ constexpr int bitrev(int x, int bits) {
   }
   return y;
 }
+
+#ifdef PDSP_STAMPS
+template <typename T, int E, int I = 0>
+__device__ __forceinline__ void pin_regs(T __attribute__((ext_vector_type(2))) (&a)[E]) {
+  if constexpr (I < E) {
+    asm volatile("" : "+v"(a[I]));
+    pin_regs<T, E, I + 1>(a);
+  }
+}
+#endif
 
 // ---- complex helpers on cx ---------------------------------------------------
 
@@ -122,9 +150,9 @@ __device__ __forceinline__ void fft_reg(cx<T> (&a)[R]) {
   });
 }
 
-template <int LOG2N>
+template <int LOG2N, int LOG2E = 4>
 struct FftTraits {
-  static constexpr RadixPlan P = make_radix_plan(LOG2N);
+  static constexpr RadixPlan P = make_radix_plan(LOG2N, LOG2E);
   static constexpr int N = P.n, E = P.e, TP = P.tp, NP = P.np;
   static constexpr int WG = TP >= 256 ? TP : 256;  // threads per workgroup
   static constexpr int ROWS = WG / TP;             // transforms per workgroup
@@ -133,6 +161,10 @@ struct FftTraits {
   static constexpr int LROW = N + N / 16;
   static constexpr int LDS_ELEMS = NP > 1 ? ROWS * LROW : 1;
 };
+
+// comma-free spelling for the __launch_bounds__ macro argument
+template <int LOG2M>
+constexpr int kPackedWG = FftTraits<LOG2M, packed_log2e(LOG2M)>::WG;
 
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
 // pad(a + c) == pad(a) + cpad(c) when c is a multiple of 16 (or a is and c < 16)
@@ -251,6 +283,99 @@ struct StoreAmplitude {  // magnitude + scaleAmplitude{One,Two}Sided [+ phase]
   }
 };
 
+// ---- twiddle providers ---------------------------------------------------------
+// twf.template get<p, r, b>(j) = W_{Ns*R}^{r*(j mod Ns)} for input r of butterfly j = tid + b*TP of pass p.
+
+// Reads the host-built table (layout: pdsp_radix.h) at every use: uniform table base per r
+// (SGPR) + one 32-bit lane offset k.
+template <typename T, int LOG2N, int LOG2E = 4>
+struct TableTwiddles {
+  const cx<T> *__restrict__ tw;
+  template <int p, int r, int b>
+  __device__ __forceinline__ cx<T> get(const int j) const {
+    using TR = FftTraits<LOG2N, LOG2E>;
+    constexpr int Ns = TR::P.ns[p];
+    return (tw + (TR::P.twoff[p] + (r - 1) * Ns))[(unsigned)(j & (Ns - 1))];
+  }
+};
+
+// a * e^{-2*pi*i*NUM/32}, NUM compile-time
+template <typename T, int NUM>
+__device__ __forceinline__ cx<T> mul_w32(const cx<T> a) {
+  constexpr int m = ((NUM % 32) + 32) % 32;
+  if constexpr (m % 2 == 0) {
+    constexpr int h = m / 2;  // W16^h
+    if constexpr (h >= 8) return -mul_w16<T, h - 8>(a);
+    else return mul_w16<T, h>(a);
+  } else {
+    // cos(pi*q/16), q = 0..8
+    constexpr double C[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                             0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                             0.19509032201612826785, 0.0};
+    constexpr int q = m % 16;
+    constexpr bool neg = m >= 16;
+    constexpr double cq = q <= 8 ? C[q] : -C[16 - q];
+    constexpr double sq = q <= 8 ? C[8 - q] : C[q - 8];
+    constexpr T c = T(neg ? -cq : cq), s = T(neg ? sq : -sq);  // W = c + i*s
+    return a.xx * cx<T>{c, s} + a.yy * cx<T>{-s, c};
+  }
+}
+
+// Per-thread twiddle BASES held in registers.  A thread's twiddles depend only on its
+// position in the transform, so they are fetched once, right behind the frame loads (their
+// L2 latency hides under the HBM wait) instead of inside every pass, where a stamped build
+// showed each table fetch exposed for thousands of cycles behind the streaming traffic.
+// Per radix-16 pass six bases {w, w^2, w^3, w^4, w^8, w^12} of the thread's own k; the other
+// nine are one product of two table-exact values.  A short last pass (Ns > TP) needs only
+// k = tid: W_N^{r*(tid + b*TP)} = base_r * W16^{r*b} because TP = N/16.
+template <typename T, int LOG2N, int LOG2E = 4>
+struct RegTwiddles {
+  using TR = FftTraits<LOG2N, LOG2E>;
+  static_assert(LOG2E == 4, "the W16 correction of the short last pass assumes TP = N/16");
+  static constexpr int nb(int p) { return TR::P.ns[p] > 1 ? (TR::P.r[p] == 16 ? 6 : TR::P.r[p] - 1) : 0; }
+  static constexpr int off(int p) {
+    int o = 0;
+    for (int i = 0; i < p; ++i) o += nb(i);
+    return o;
+  }
+  static constexpr int TOTAL = off(TR::NP) > 0 ? off(TR::NP) : 1;
+  // which power r the i-th base of a radix-R pass holds: 16 -> 1,2,3,4,8,12; else 1..R-1
+  static constexpr int base_r(int R, int i) { return R == 16 ? (i < 4 ? i + 1 : (i - 2) * 4) : i + 1; }
+
+  cx<T> tb[TOTAL];
+
+  __device__ __forceinline__ void load(const cx<T> *__restrict__ tw, const int tid) {
+    static_for<TR::NP>([&](auto pc) {
+      constexpr int p = pc;
+      constexpr int Ns = TR::P.ns[p], R = TR::P.r[p];
+      if constexpr (Ns > 1) {
+        // Ns <= TP for every pass but a short last one, where j = tid + b*TP < Ns
+        const unsigned k0 = (unsigned)(Ns <= TR::TP ? (tid & (Ns - 1)) : tid);
+        static_for<nb(p)>([&](auto ic) {
+          constexpr int r = base_r(R, ic);
+          tb[off(p) + ic] = (tw + (TR::P.twoff[p] + (r - 1) * Ns))[k0];
+        });
+      }
+    });
+  }
+
+  template <int p, int r, int b>
+  __device__ __forceinline__ cx<T> get(const int) const {
+    constexpr int Ns = TR::P.ns[p], R = TR::P.r[p], O = off(p);
+    cx<T> w;
+    if constexpr (R == 16) {
+      constexpr int hi = r & 12, lo = r & 3;
+      if constexpr (hi == 0) w = tb[O + lo - 1];
+      else if constexpr (lo == 0) w = tb[O + 2 + hi / 4];
+      else w = cmul(tb[O + 2 + hi / 4], tb[O + lo - 1]);  // w^(hi+lo) = w^hi * w^lo
+    } else {
+      w = tb[O + r - 1];
+    }
+    if constexpr (Ns > TR::TP && b > 0) w = mul_w32<T, 2 * ((r * b) % 16)>(w);  // * W16^{r*b}
+    return w;
+  }
+};
+
 // ---- the passes --------------------------------------------------------------
 
 // Runs every pass of the length-2^LOG2N transform on the E points each of the TP
@@ -258,12 +383,13 @@ struct StoreAmplitude {  // magnitude + scaleAmplitude{One,Two}Sided [+ phase]
 // registers, X[tid + TP*q] in slot q.  LAST_TO_LDS = true: the last pass also
 // scatters to LDS, in natural order (X[k] at lds_pad(k)), for a consumer that needs
 // other threads' bins; the caller must __syncthreads() before reading it.
-// Inter-pass twiddles W_{Ns*R}^{r*k} come from the host-built table (pdsp_radix.h).
-template <typename T, int LOG2N, bool LAST_TO_LDS>
-__device__ __forceinline__ void fft_passes(cx<T> (&x)[FftTraits<LOG2N>::E], cx<T> *const lrow,
-                                           const cx<T> *__restrict__ tw, const int tid) {
-  using TR = FftTraits<LOG2N>;
+// Inter-pass twiddles W_{Ns*R}^{r*k} come from the provider `twf` (table or registers).
+template <typename T, int LOG2N, bool LAST_TO_LDS, int LOG2E = 4, class TWF = void, int EE = 0>
+__device__ __forceinline__ void fft_passes(cx<T> (&x)[EE], cx<T> *const lrow, const TWF &twf, const int tid) {
+  PDSP_STAMP_INIT();
+  using TR = FftTraits<LOG2N, LOG2E>;
   constexpr int E = TR::E, TP = TR::TP, NP = TR::NP;
+  static_assert(EE == E, "register array size must be the plan's points per thread");
   // For N >= 256 every LDS address is (a thread-only base) + (a compile-time offset),
   // so there is one address register per pass instead of one per element.
   constexpr bool kConstOffsets = (TP % 16 == 0);
@@ -280,32 +406,34 @@ __device__ __forceinline__ void fft_passes(cx<T> (&x)[FftTraits<LOG2N>::E], cx<T
       static_for<R>([&](auto rc) { a[rc] = x[b + rc * EB]; });
       const int j = tid + b * TP;  // butterfly index within the pass, 0 <= j < N/R
       if constexpr (Ns > 1) {
-        // uniform table base per r (SGPR) + one 32-bit lane offset k: no 64-bit VALU adds
-        const unsigned k = (unsigned)(j & (Ns - 1));
         static_for<R - 1>([&](auto rc) {
           constexpr int r = rc + 1;
-          a[r] = cmul(a[r], (tw + (TR::P.twoff[p] + (r - 1) * Ns))[k]);
+          a[r] = cmul(a[r], twf.template get<p, r, b>(j));
         });
       }
       fft_reg<T, R>(a);
       if constexpr (!to_lds) {
         // Ns*R == N: output r of butterfly j is X[j + r*N/R] = slot b + r*EB
         static_for<R>([&](auto rc) { x[b + rc * EB] = a[bitrev(rc, LR)]; });
-      } else if constexpr (kConstOffsets && (Ns % 16 == 0 || (Ns == 1 && R == 16))) {
-        // autosort scatter (natural order when Ns*R == N).  j = tid + b*TP: the part of
-        // the index that depends on b and rc is a compile-time constant
+      } else if constexpr (kConstOffsets) {
+        // autosort scatter (natural order when Ns*R == N).  j = tid + b*TP: the part of the
+        // index that depends on b and rc is the constant c = cb + rc*Ns, and
+        // pad(j0t + c) == pad(j0t) + cpad(c): cb is a multiple of 16, and (j0t & 15) + (rc*Ns & 15)
+        // never carries (for Ns < 16 the first is < Ns, the second a multiple of Ns below 16)
         constexpr int cb = Ns <= TP ? b * TP * R : b * TP;
         const int j0t = Ns <= TP ? ((tid >> ilog2(Ns)) << ilog2(Ns * R)) + (tid & (Ns - 1)) : tid;
         cx<T> *const wbase = lrow + lds_pad(j0t);
-        static_for<R>([&](auto rc) { wbase[Ns == 1 ? cpad(cb) + rc : cpad(cb + rc * Ns)] = a[bitrev(rc, LR)]; });
+        static_for<R>([&](auto rc) { wbase[cpad(cb + rc * Ns)] = a[bitrev(rc, LR)]; });
       } else {
         const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
         static_for<R>([&](auto rc) { lrow[lds_pad(j0 + rc * Ns)] = a[bitrev(rc, LR)]; });
       }
     });
 
+    PDSP_STAMP(8 + 4 * p);  // twiddle loads + butterflies + LDS scatter issued
     if constexpr (!last) {
       __syncthreads();
+      PDSP_STAMP(9 + 4 * p);  // barrier (incl. draining the scatter)
       if constexpr (kConstOffsets) {
         const cx<T> *const rbase = lrow + lds_pad(tid);
         static_for<E>([&](auto q) { x[q] = rbase[cpad(TP * q)]; });
@@ -314,6 +442,7 @@ __device__ __forceinline__ void fft_passes(cx<T> (&x)[FftTraits<LOG2N>::E], cx<T
       }
       // the next pass writes LDS again (every pass but a register-resident last one)
       if constexpr (p + 1 < NP - 1 || LAST_TO_LDS) __syncthreads();
+      PDSP_STAMP(10 + 4 * p);  // LDS read-back issued + barrier
     }
   });
 }
@@ -366,7 +495,7 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
 
   cx<T> x[E];
   static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
-  fft_passes<T, LOG2N, false>(x, lrow, reinterpret_cast<const cx<T> *>(tw), tid);
+  fft_passes<T, LOG2N, false>(x, lrow, TableTwiddles<T, LOG2N>{reinterpret_cast<const cx<T> *>(tw)}, tid);
   if (live) {
     static_for<E>([&](auto q) { st(row, TP * q, tid, x[q]); });
   }
@@ -389,13 +518,14 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
 //   PEAK: also reduce each frame to its SpectrumPeak (findPeak fused; `amp` may then be
 //         null = peaks-only output, 16 B per frame instead of 2*(N/2+1) B).
 template <typename T, int LOG2M, bool FAST, bool HAS_WIN, bool PEAK>
-__global__ void __launch_bounds__(FftTraits<LOG2M>::WG)
+__global__ void __launch_bounds__(kPackedWG<LOG2M>)
 spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, const long long frame_len,
                        const long long stride, const typename vec2<T>::type *__restrict__ tw,
                        const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp,
                        T *__restrict__ ph, const int two_sided, const T s_edge, const T s_mid,
                        PeakRec *__restrict__ peaks, const T freq_scale, const long long batch) {
-  using TR = FftTraits<LOG2M>;
+  constexpr int LOG2E = packed_log2e(LOG2M);
+  using TR = FftTraits<LOG2M, LOG2E>;
   constexpr int E = TR::E, TP = TR::TP, M = TR::N;
   static_assert(LOG2M >= 5, "packed path needs TP >= 2");
 
@@ -424,19 +554,31 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       x[q] = cx<T>{i0 < flen ? v0 : T(0), i0 + 1 < flen ? v1 : T(0)};
     });
   }
+  PDSP_STAMP_INIT();
+  // twiddle bases: issued right behind the frame loads, consumed passes later
+  constexpr bool kRegTw = (LOG2E == 4 && TP >= 16);
+  std::conditional_t<kRegTw, RegTwiddles<T, LOG2M, LOG2E>, TableTwiddles<T, LOG2M, LOG2E>> twf;
+  if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  else twf.tw = reinterpret_cast<const cx<T> *>(tw);
+  // W_N^tid: the Hermitian split needs W_N^(tid + TP*q) = twk0 * W32^q (N = 32*TP)
+  const cx<T> twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
   if constexpr (HAS_WIN) {
     const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
     static_for<E>([&](auto q) { x[q] = x[q] * (w2 + TP * q)[(unsigned)tid]; });
   }
+#ifdef PDSP_STAMPS
+  pin_regs<T, E>(x);  // land the frame + window here
+#endif
+  PDSP_STAMP(0);  // frame + window loads
 
-  fft_passes<T, LOG2M, true>(x, lrow, reinterpret_cast<const cx<T> *>(tw), tid);
+  fft_passes<T, LOG2M, true, LOG2E>(x, lrow, twf, tid);
   __syncthreads();
+  PDSP_STAMP(1);  // all passes (detail in slots 8..)
 
   const int bins = (!FAST && two_sided) ? 2 * M : M + 1;
   const bool store_amp = live && (!PEAK || amp != nullptr);
   T *const arow = amp + (size_t)row * (size_t)bins;
   T *const prow = (!FAST && ph) ? ph + (size_t)row * (size_t)bins : nullptr;
-  const cx<T> *const twk = reinterpret_cast<const cx<T> *>(twr);
   PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);
   cx<T> dc_x{T(0), T(0)};
@@ -457,7 +599,9 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
         z = lrow[lds_pad(k)];
         zp = lrow[lds_pad(k2 & (M - 1))];
       }
-      const cx<T> w = (twk + TP * q)[(unsigned)tid];       // W_N^k
+      cx<T> w;                                             // W_N^k
+      if constexpr (LOG2E == 4) w = mul_w32<T, q>(twk0);   // N = 32*TP: W_N^(TP*q) = W32^q
+      else w = (reinterpret_cast<const cx<T> *>(twr) + TP * q)[(unsigned)tid];
       const cx<T> e = (z + conj(zp)) * T(0.5);             // E
       const cx<T> o = mul_neg_i(z - conj(zp)) * T(0.5);    // O = (Z - conj Zp)/(2i)
       const cx<T> t = cmul(o, w);
@@ -498,6 +642,7 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     }
   });
 
+  PDSP_STAMP(2);  // Hermitian split + stores issued
   if constexpr (PEAK) {
     // row-wide arg-max: butterflies inside the wave, then one LDS hop across the row's waves
     constexpr int WSPAN = TP < 64 ? TP : 64;

@@ -11,7 +11,7 @@
 
 namespace pdsp {
 
-constexpr int kMaxPasses = 4;
+constexpr int kMaxPasses = 5;
 constexpr int kMaxLog2N_f32 = 14;  // (N + N/16) * 8 B of LDS <= 160 KiB
 constexpr int kMaxLog2N_f64 = 13;  // (N + N/16) * 16 B
 constexpr int kMaxLog2N1 = 4;      // four-step path: N = N1 * N2, N1 <= 16 columns per thread
@@ -28,21 +28,23 @@ struct RadixPlan {
   int twcount;         // total table entries (complex)
 };
 
-constexpr RadixPlan make_radix_plan(int log2n) {
+// log2e: points per thread (4 = sixteen, the default; 3 = eight: half the registers, twice the
+// waves, one more LDS pass -- what the VALU-issue-bound packed-real kernel at M = 8192 wants).
+constexpr RadixPlan make_radix_plan(int log2n, int log2e = 4) {
   RadixPlan p{};
   p.log2n = log2n;
   p.n = 1 << log2n;
-  if (log2n <= 4) {
+  if (log2n <= log2e) {
     p.e = p.n;
     p.tp = 1;
     p.np = log2n == 0 ? 0 : 1;
     p.r[0] = p.n;
   } else {
-    p.e = 16;
-    p.tp = p.n / 16;
-    const int full = log2n / 4, rem = log2n % 4;
+    p.e = 1 << log2e;
+    p.tp = p.n >> log2e;
+    const int full = log2n / log2e, rem = log2n % log2e;
     p.np = full + (rem ? 1 : 0);
-    for (int i = 0; i < full; ++i) p.r[i] = 16;
+    for (int i = 0; i < full; ++i) p.r[i] = 1 << log2e;
     if (rem) p.r[full] = 1 << rem;
   }
   int ns = 1, off = 0;
@@ -58,5 +60,11 @@ constexpr RadixPlan make_radix_plan(int log2n) {
   p.twcount = off;
   return p;
 }
+
+// Points per thread of the packed-real spectrum kernel, by log2 of its N/2-point transform.
+#ifndef PDSP_PACKED_LOG2E_13
+#define PDSP_PACKED_LOG2E_13 4  /* 3 (eight points per thread, 8 waves/SIMD) measured 6 % slower: tools/kbench */
+#endif
+constexpr int packed_log2e(int log2m) { return log2m == 13 ? PDSP_PACKED_LOG2E_13 : 4; }
 
 }  // namespace pdsp

@@ -53,8 +53,8 @@ __global__ void __launch_bounds__(256) copy_float4(const float4 *__restrict__ in
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) out[i] = in[i];
 }
 
-static void fill_tw(int log2n, std::vector<float2> &tw) {
-  const pdsp::RadixPlan p = pdsp::make_radix_plan(log2n);
+static void fill_tw(int log2n, std::vector<float2> &tw, int log2e = 4) {
+  const pdsp::RadixPlan p = pdsp::make_radix_plan(log2n, log2e);
   tw.assign(p.twcount > 0 ? p.twcount : 1, make_float2(1, 0));
   for (int i = 0; i < p.np; ++i) {
     if (p.ns[i] <= 1) continue;
@@ -86,22 +86,22 @@ static int spec_main(long long frames, int rounds) {
     CK(hipMemcpy(win, w.data(), n * 4, hipMemcpyHostToDevice));
   }
   std::vector<float2> tw, twr(m / 2 + 1);
-  fill_tw(13, tw);
+  fill_tw(13, tw, pdsp::packed_log2e(13));
   for (int k = 0; k <= m / 2; ++k) twr[k] = make_float2((float)cos(-2 * M_PI * k / n), (float)sin(-2 * M_PI * k / n));
   float2 *dtw, *dtwr;
   CK(hipMalloc(&dtw, tw.size() * 8));
   CK(hipMemcpy(dtw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dtwr, twr.size() * 8));
   CK(hipMemcpy(dtwr, twr.data(), twr.size() * 8, hipMemcpyHostToDevice));
-  using TR = pdsp::FftTraits<13>;
+  using TR = pdsp::FftTraits<13, pdsp::packed_log2e(13)>;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<float> ms;
   auto run = [&] {
-    hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
+    hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true, false>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
                        dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
-                       1.0f / n, 2.0f / n, frames);
+                       1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
   };
   for (int i = 0; i < 20; ++i) run();
   CK(hipDeviceSynchronize());
@@ -115,6 +115,24 @@ static int spec_main(long long frames, int rounds) {
     ms.push_back(t / 5);
   }
   CK(hipGetLastError());
+#ifdef PDSP_STAMPS
+  {
+    unsigned long long z[64] = {0}, acc[64];
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(pdsp::pdsp_stamp_acc), z, sizeof(z)));
+    run();
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(pdsp::pdsp_stamp_acc), sizeof(acc)));
+    const double wgs = (double)((frames + TR::ROWS - 1) / TR::ROWS);
+    const char *names[] = {"load+window", "passes total", "split+stores"};
+    double tot = 0;
+    for (int i = 0; i < 3; ++i) tot += acc[i] / wgs;
+    for (int i = 0; i < 3; ++i) printf("  %-14s %9.0f cycles/WG  %5.1f %%\n", names[i], acc[i] / wgs, 100.0 * acc[i] / wgs / tot);
+    for (int p = 0; p < 5; ++p)
+      if (acc[8 + 4 * p])
+        printf("    pass %d: compute+scatter %8.0f   barrier %8.0f   readback+barrier %8.0f\n", p, acc[8 + 4 * p] / wgs,
+               acc[9 + 4 * p] / wgs, acc[10 + 4 * p] / wgs);
+  }
+#endif
   std::sort(ms.begin(), ms.end());
   const double bytes = (4.0 * n + 4.0 * bins) * frames;
   printf("spectrum16k frames=%lld  med %.4f ms  min %.4f ms  med %.1f GB/s  max %.1f GB/s\n", frames, ms[ms.size() / 2], ms[0], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
