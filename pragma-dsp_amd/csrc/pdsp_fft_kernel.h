@@ -495,7 +495,15 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
 
   cx<T> x[E];
   static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
-  fft_passes<T, LOG2N, false>(x, lrow, TableTwiddles<T, LOG2N>{reinterpret_cast<const cx<T> *>(tw)}, tid);
+#ifndef PDSP_C2C_TABLE_TWIDDLES
+  constexpr bool kRegTw = (TP >= 16 && NP > 1);  // twiddle bases in registers, fetched behind the row loads
+#else
+  constexpr bool kRegTw = false;
+#endif
+  std::conditional_t<kRegTw, RegTwiddles<T, LOG2N>, TableTwiddles<T, LOG2N>> twf;
+  if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  else twf.tw = reinterpret_cast<const cx<T> *>(tw);
+  fft_passes<T, LOG2N, false>(x, lrow, twf, tid);
   if (live) {
     static_for<E>([&](auto q) { st(row, TP * q, tid, x[q]); });
   }
