@@ -92,6 +92,11 @@ PDSP_API int pdsp_device_count(void);
  * real-frame spectrum) one LDS-resident pass; above, a three-pass four-step transform. */
 PDSP_API int pdsp_max_size(int scalar_bytes);
 
+/* Kernel selection switch for A/B tests (process-wide; returns the previous value): 1 (default)
+ * runs whole aligned one-sided N = 16384 f32 spectra on spectrum_split16k_kernel (two 4096-point
+ * sub-transforms per workgroup); 0 on spectrum_packed_kernel<13>.  Same results within rounding. */
+PDSP_API int pdsp_set_split16k(int enabled);
+
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).
  *   64 (default): f64 on the device for every size up to 2^17 -- the drop-in then meets the
  *       reference's own test tolerances (1e-10 against NumPy, signals.test.ts:22-23), not just the

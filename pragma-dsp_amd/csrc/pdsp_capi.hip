@@ -23,6 +23,8 @@
 namespace {
 
 thread_local std::string g_err;
+// development switch (tools / tests): 0 routes N = 16384 spectra to spectrum_packed_kernel<13>
+int g_split16k = 1;
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -74,6 +76,7 @@ struct Tables {
   // split twiddles W_N^k, 0 <= k <= N/4
   T2 *tw_half = nullptr;
   T2 *twr = nullptr;
+  T2 *tw12 = nullptr;  // N = 16384 only: radix table of the 4096-point sub-transforms (split kernel)
   T *win[4] = {nullptr, nullptr, nullptr, nullptr};  // createWindow(type, N), built on first use
   // four-step path (N beyond the single-pass limit): `tw` then belongs to the N2-point rows,
   // N1 = N / N2, and W_N^m = twa[m >> 9] * twb[m & 511]
@@ -82,6 +85,8 @@ struct Tables {
   T2 *twa = nullptr;
   T2 *twb = nullptr;
   void release() {
+    if (tw12) (void)hipFree(tw12);
+    tw12 = nullptr;
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
     twa = twb = nullptr;
@@ -466,6 +471,11 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
     if (e == hipSuccess) e = hipMemcpy(t.tw_half, twh.data(), twh.size() * sizeof(T2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&t.twr, twr.size() * sizeof(T2));
     if (e == hipSuccess) e = hipMemcpy(t.twr, twr.data(), twr.size() * sizeof(T2), hipMemcpyHostToDevice);
+    if (e == hipSuccess && log2n == 14) {
+      const std::vector<T2> t12 = build_twiddles<T2>(12);
+      e = hipMalloc((void **)&t.tw12, t12.size() * sizeof(T2));
+      if (e == hipSuccess) e = hipMemcpy(t.tw12, t12.data(), t12.size() * sizeof(T2), hipMemcpyHostToDevice);
+    }
   }
   return e;
 }
@@ -559,6 +569,23 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     // fast variant: whole pair-aligned frames, one-sided, no phase rows (config 4's shape)
     const bool fast = ((uintptr_t)frames & kPairMask) == 0 && (frame_stride & 1) == 0 && used == n &&
                       sides == PDSP_SIDES_ONE && phase_out == nullptr;
+    if constexpr (sizeof(T) == 4) {
+      // N = 16384: two 4096-point sub-transforms per 256-thread workgroup (4 frames per CU instead of 2)
+      if (fast && plan->log2n == 14 && g_split16k && ((uintptr_t)frames & 15) == 0 && (frame_stride & 3) == 0 &&
+          (window == nullptr || ((uintptr_t)window & 15) == 0)) {
+        pdsp::PeakRec *pk = reinterpret_cast<pdsp::PeakRec *>(peaks_out);
+#define PDSP_SPLIT(W, P)                                                                                         \
+  hipLaunchKernelGGL((pdsp::spectrum_split16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames, \
+                     window, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch)
+        if (window && pk) PDSP_SPLIT(true, true);
+        else if (window) PDSP_SPLIT(true, false);
+        else if (pk) PDSP_SPLIT(false, true);
+        else PDSP_SPLIT(false, false);
+#undef PDSP_SPLIT
+        PDSP_HIP_TRY(hipGetLastError());
+        return PDSP_OK;
+      }
+    }
     PDSP_HIP_TRY(launch_packed<T>(plan->log2n - 1, fast, frames, window, used, frame_stride, t.tw_half, t.twr, amp_out,
                                   phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
                                   reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
@@ -719,6 +746,12 @@ int pdsp_max_size(int scalar_bytes) {  // incl. the four-step path
   if (scalar_bytes == 4) return 1 << (pdsp::kMaxLog2N_f32 + pdsp::kMaxLog2N1);
   if (scalar_bytes == 8) return 1 << (pdsp::kMaxLog2N_f64 + pdsp::kMaxLog2N1);
   return 0;
+}
+
+int pdsp_set_split16k(int enabled) {
+  const int prev = g_split16k;
+  g_split16k = enabled ? 1 : 0;
+  return prev;
 }
 
 int pdsp_set_host_precision(int bits) {

@@ -877,6 +877,178 @@ complex_op_kernel(const T *__restrict__ are, const T *__restrict__ aim, const T 
   }
 }
 
+// a * e^{-2*pi*i*NUM/64}, NUM compile-time (0 <= NUM < 16 is all the split kernel needs)
+template <typename T, int NUM>
+__device__ __forceinline__ cx<T> mul_w64(const cx<T> a) {
+  static_assert(NUM >= 0 && NUM < 32, "first half turn only");
+  if constexpr (NUM % 2 == 0) {
+    return mul_w32<T, NUM / 2>(a);
+  } else {
+    // cos(pi*j/32), j = 0..16
+    constexpr double C[17] = {1.0,
+                              0.99518472667219688624, 0.98078528040323044913, 0.95694033573220886494,
+                              0.92387953251128675613, 0.88192126434835502971, 0.83146961230254523708,
+                              0.77301045336273696081, 0.70710678118654752440, 0.63439328416364549822,
+                              0.55557023301960222474, 0.47139673682599764856, 0.38268343236508977173,
+                              0.29028467725446236764, 0.19509032201612826785, 0.09801714032956060199,
+                              0.0};
+    constexpr double cq = NUM <= 16 ? C[NUM] : -C[32 - NUM];
+    constexpr double sq = NUM <= 16 ? C[16 - NUM] : C[NUM - 16];
+    constexpr T c = T(cq), s = T(-sq);  // W = cos - i sin
+    return a.xx * cx<T>{c, s} + a.yy * cx<T>{-s, c};
+  }
+}
+
+// spectrum() body for N = 16384 real frames, the config-4 shape (whole 16-byte-aligned frames,
+// one-sided amplitude, optional fused findPeak), re-cut so that FOUR frames fit a CU.
+// The packed transform Z = FFT_8192(z), z[m] = x[2m] + i*x[2m+1], is taken as one radix-2
+// decimation-in-time step over two 4096-point transforms that the SAME 256 threads run back
+// to back through one 4096-point LDS buffer:
+//   one 16-byte load gives (z[2m], z[2m+1]) = (even[m], odd[m]);  Ev = FFT_4096(even),
+//   Od = FFT_4096(odd);  Z[k] = Ev[k] + W_8192^k Od[k],  Z[k+4096] = Ev[k] - W_8192^k Od[k]
+//   in registers (thread tid holds k = tid + 256q of both).
+// The Hermitian split pairs Z[k] (k < 4096, in registers) with Z[8192-k] (upper half), so only
+// the upper half goes through LDS, once.  Versus spectrum_packed_kernel<13>: 34.8 KB instead of
+// 69.6 KB of LDS (4 workgroups per CU instead of 2, 4-wave instead of 8-wave barriers) and 2.5
+// instead of 5 full-size LDS round trips per frame.
+#ifndef PDSP_SPLIT16K_WAVES
+#define PDSP_SPLIT16K_WAVES 2  // 2 workgroups per CU (177 VGPRs); 3 and 4 spill and measured slower (tools/kbench)
+#endif
+template <typename T, bool HAS_WIN, bool PEAK>
+__global__ void __launch_bounds__(256, PDSP_SPLIT16K_WAVES)
+spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, const long long stride,
+                         const typename vec2<T>::type *__restrict__ tw12,
+                         const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp, const T s_edge,
+                         const T s_mid, PeakRec *__restrict__ peaks, const T freq_scale, const long long batch) {
+  using TR = FftTraits<12>;
+  constexpr int E = 16, TP = 256, H = 4096, M = 8192;
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[TR::LROW];
+
+  const int tid = (int)threadIdx.x;
+  const long long row = uniform_row<TP>((long long)blockIdx.x);
+  if (row >= batch) return;
+  const cx<T> *const tw = reinterpret_cast<const cx<T> *>(tw12);
+  const cx<T> *const twn = reinterpret_cast<const cx<T> *>(twr);  // W_16384^k, k <= 4096
+
+  // one 16-byte load per point pair; m = tid + 256*q
+  const V4 *const x4 = reinterpret_cast<const V4 *>(frames + (size_t)row * (size_t)stride);
+  cx<T> a[E], b[E];
+  static_for<E>([&](auto q) {
+    const V4 v = ld_stream(x4 + TP * q + (unsigned)tid);
+    a[q] = cx<T>{v.x, v.y};
+    b[q] = cx<T>{v.z, v.w};
+  });
+  // twiddle bases right behind the frame loads (see RegTwiddles)
+  RegTwiddles<T, 12> twf;
+  twf.load(tw, tid);
+  const cx<T> wc0 = twn[(unsigned)(2 * tid)];  // W_8192^tid  (combine: W_8192^(tid+256q) = wc0 * W32^q)
+  const cx<T> ws0 = twn[(unsigned)tid];        // W_16384^tid (split:   W_16384^(tid+256q) = ws0 * W64^q)
+  if constexpr (HAS_WIN) {
+    const V4 *const w4 = reinterpret_cast<const V4 *>(win);
+    static_for<E>([&](auto q) {
+      const V4 w = (w4 + TP * q)[(unsigned)tid];
+      a[q] = a[q] * cx<T>{w.x, w.y};
+      b[q] = b[q] * cx<T>{w.z, w.w};
+    });
+  }
+
+  fft_passes<T, 12, false>(a, lds, twf, tid);  // a[q] = Ev[tid + 256q]
+  __syncthreads();                            // the buffer is reused by the second transform
+  fft_passes<T, 12, false>(b, lds, twf, tid);  // b[q] = Od[tid + 256q]
+
+  // radix-2 combine in registers: a <- Z[k], b <- Z[k + 4096]
+  static_for<E>([&](auto q) {
+    const cx<T> t = cmul(b[q], mul_w32<T, q>(wc0));
+    b[q] = a[q] - t;
+    a[q] = a[q] + t;
+  });
+  // upper half -> LDS (natural order) for the partners Z[8192 - k]
+  __syncthreads();
+  {
+    cx<T> *const wbase = lds + lds_pad(tid);
+    static_for<E>([&](auto q) { wbase[cpad(TP * q)] = b[q]; });
+  }
+  __syncthreads();
+
+  T *const arow = amp + (size_t)row * (size_t)(M + 1);
+  const bool store_amp = !PEAK || amp != nullptr;
+  PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
+  T dc_amp = T(0);
+  cx<T> dc_x{T(0), T(0)};
+  // pairs (k, 8192-k), k = tid + 256q < 4096.  Partner Z[8192-k] = upper[4096-k] for k >= 1;
+  // k = 0 pairs with itself (DC and Nyquist).  upper[4096-k] sits at pad(4096 - tid) - q*cpad(256).
+  const cx<T> *const uhi = lds + lds_pad(H - tid);
+  static_for<E>([&](auto qc) {
+    constexpr int q = qc;
+    const int k = tid + TP * q;
+    const cx<T> z = a[q];
+    cx<T> zp;
+    if constexpr (q == 0) zp = tid == 0 ? z : uhi[0];
+    else zp = *(uhi - cpad(TP * q));
+    const cx<T> w = mul_w64<T, q>(ws0);                  // W_N^k
+    const cx<T> e = (z + conj(zp)) * T(0.5);
+    const cx<T> o = mul_neg_i(z - conj(zp)) * T(0.5);
+    const cx<T> t = cmul(o, w);
+    const cx<T> xa = e + t;                              // X[k]
+    const cx<T> xb = conj(e - t);                        // X[8192 - k]
+    const T sc = (k == 0) ? s_edge : s_mid;              // DC and Nyquist are not doubled
+    const T ma = mag(xa) * sc, mb = mag(xb) * sc;
+    if constexpr (PEAK) {
+      if (k == 0) {
+        dc_amp = ma;
+        dc_x = xa;
+      } else {
+        best.consider(ma, k, xa);
+      }
+      best.consider(mb, M - k, xb);
+    }
+    if (store_amp) {
+      st_rowtail(ma, arow + (unsigned)k);
+      st_rowtail(mb, arow + (unsigned)(M - k));
+    }
+  });
+  // the middle bin k = 4096 pairs with itself: X[4096] = conj(Z[4096]) = conj(upper[0]) (thread 0's b[0])
+  if (tid == 0) {
+    const cx<T> xm = conj(b[0]);
+    const T mm = mag(xm) * s_mid;
+    if constexpr (PEAK) best.consider(mm, H, xm);
+    if (store_amp) st_rowtail(mm, arow + (unsigned)H);
+  }
+
+  if constexpr (PEAK) {
+    static_for<6>([&](auto sc) {
+      constexpr int off = 32 >> sc;
+      PeakBest<T> o;
+      o.v = __shfl_xor(best.v, off, 64);
+      o.i = __shfl_xor(best.i, off, 64);
+      o.x = cx<T>{__shfl_xor(best.x.x, off, 64), __shfl_xor(best.x.y, off, 64)};
+      best.consider(o.v, o.i, o.x);
+    });
+    __shared__ T pk_v[4];
+    __shared__ int pk_i[4];
+    __shared__ cx<T> pk_x[4];
+    const int wave = tid / 64;
+    if ((tid & 63) == 0) {
+      pk_v[wave] = best.v;
+      pk_i[wave] = best.i;
+      pk_x[wave] = best.x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      static_for<3>([&](auto wc) { best.consider(pk_v[wc + 1], pk_i[wc + 1], pk_x[wc + 1]); });
+      const bool none = best.i == 0;
+      const cx<T> px = none ? dc_x : best.x;
+      PeakRec r;
+      r.index = best.i;
+      r.frequency = (float)(T(best.i) * freq_scale);
+      r.amplitude = (float)(none ? dc_amp : best.v);
+      r.phase = (float)atan2(px.y, px.x);
+      peaks[row] = r;
+    }
+  }
+}
+
 // SpectrumPeak per frame from stored amplitude (and phase) rows: the fallback of the fused
 // PEAK path for sizes / alignments the packed kernel does not take.  One workgroup per row.
 template <typename T>

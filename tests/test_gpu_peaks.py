@@ -32,7 +32,12 @@ def test_peaks_match_oracle(oracle_mod, log2n, sides):
     idx2, freq2, amp2, ph2, none_a, none_p = plan.spectrum_peaks(dx, window, sides, fs)  # peaks only
     torch.cuda.synchronize()
     assert none_a is None and none_p is None
-    assert torch.equal(idx, idx2) and torch.equal(amp_pk, amp2) and torch.equal(freq, freq2) and torch.equal(ph_pk, ph2)
+    # the two calls may run different kernel variants (phase rows force the general one): same peaks,
+    # values equal to rounding
+    assert torch.equal(idx, idx2) and torch.equal(freq, freq2)
+    assert float((amp_pk - amp2).abs().max()) <= 2e-6 * float(amp_pk.abs().max() + 1e-30)
+    big = (amp_pk > 1e-3 * amp_pk.max()).to(ph_pk.dtype)  # phase of a zero peak is a signed-zero artefact
+    assert float((((ph_pk - ph2 + np.pi) % (2 * np.pi) - np.pi).abs() * big).max()) <= 1e-4
     win = oracle_mod.create_window(window, n).astype(np.float32) if (window != "rect" and n > 1) else None
     wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, two_sided=(sides == "two"),
                                                        want_phase=True, want_peak=True)

@@ -113,3 +113,40 @@ def test_spectrum_full_size_properties():
     assert float(((energy - want).abs() / want).max()) < 1e-5
     amp3, _, _ = plan.spectrum(3 * x, "rect", "one")
     assert float(((amp3 - 3 * amp).abs().amax(dim=1) / amp3.amax(dim=1)).max()) < 1e-6
+
+
+@pytest.mark.parametrize("window", ["rect", "hann"])
+def test_split16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, window):
+    """N = 16384 whole aligned frames run on spectrum_split16k_kernel (two 4096-point sub-transforms
+    per workgroup); pdsp_set_split16k(0) routes the same call to spectrum_packed_kernel<13>."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 16384
+    rng = np.random.default_rng(16)
+    t = np.arange(n)
+    x = (rng.standard_normal((9, n)) * 0.3 + np.sin(2 * np.pi * 777 * t / n)[None, :]).astype(np.float32)
+    x[7] = 0.0          # zeros: exact zeros, peak 0
+    x[8] = 1.0          # DC: peak stays at bin 0
+    dx = torch.from_numpy(x).cuda()
+    plan = BatchedFft(n, "cuda:0")
+    win = oracle_mod.create_window(window, n).astype(np.float32) if window != "rect" else None
+    wamp, _, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, want_peak=True)
+    res = {}
+    for mode in (1, 0):
+        prev = pdsp.lib.pdsp_set_split16k(mode)
+        try:
+            amp, _, _ = plan.spectrum(dx, window, "one")
+            idx, freq, pamp, pph, _, _ = plan.spectrum_peaks(dx, window, "one", 48000.0)
+            torch.cuda.synchronize()
+        finally:
+            pdsp.lib.pdsp_set_split16k(prev)
+        res[mode] = (amp.cpu().numpy(), idx.cpu().numpy(), pamp.cpu().numpy(), pph.cpu().numpy())
+        assert rel_err(res[mode][0][:7], wamp[:7]) <= TOL
+        assert not res[mode][0][7].any() and res[mode][1][7] == 0 and res[mode][2][7] == 0
+        # DC frame: bin 0 with a rect window; with Hann the window's own bin 1 wins (findPeak skips DC)
+        assert res[mode][1][8] == wpk[8] == (0 if window == "rect" else 1)
+        assert abs(res[mode][2][8] - wamp[8, wpk[8]]) < 1e-5
+        assert list(res[mode][1][:7]) == list(wpk[:7]) == [777] * 7
+        assert np.array_equal(res[mode][0][np.arange(7), res[mode][1][:7]], res[mode][2][:7])
+    assert rel_err(res[1][0][:7], res[0][0][:7]) <= 2e-6          # the two kernels agree to rounding
+    assert np.abs(((res[1][3][:7] - res[0][3][:7]) + np.pi) % (2 * np.pi) - np.pi).max() < 1e-4

@@ -85,9 +85,9 @@ static int spec_main(long long frames, int rounds) {
     for (int i = 0; i < n; ++i) w[i] = (float)(0.5 * (1 - cos(2 * M_PI * i / (n - 1))));
     CK(hipMemcpy(win, w.data(), n * 4, hipMemcpyHostToDevice));
   }
-  std::vector<float2> tw, twr(m / 2 + 1);
+  std::vector<float2> tw, twr(n / 4 + 1);
   fill_tw(13, tw, pdsp::packed_log2e(13));
-  for (int k = 0; k <= m / 2; ++k) twr[k] = make_float2((float)cos(-2 * M_PI * k / n), (float)sin(-2 * M_PI * k / n));
+  for (int k = 0; k <= n / 4; ++k) twr[k] = make_float2((float)cos(-2 * M_PI * k / n), (float)sin(-2 * M_PI * k / n));
   float2 *dtw, *dtwr;
   CK(hipMalloc(&dtw, tw.size() * 8));
   CK(hipMemcpy(dtw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
@@ -98,7 +98,18 @@ static int spec_main(long long frames, int rounds) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<float> ms;
+  std::vector<float2> tw12;
+  fill_tw(12, tw12);
+  float2 *dtw12;
+  CK(hipMalloc(&dtw12, tw12.size() * 8));
+  CK(hipMemcpy(dtw12, tw12.data(), tw12.size() * 8, hipMemcpyHostToDevice));
+  const bool split = getenv("KB_SPLIT") != nullptr;
   auto run = [&] {
+    if (split) {
+      hipLaunchKernelGGL((pdsp::spectrum_split16k_kernel<float, true, false>), dim3(frames), dim3(256), 0, 0, x, win,
+                         (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
+      return;
+    }
     hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true, false>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
                        dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
                        1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
