@@ -227,7 +227,7 @@ def main() -> int:
         im = None
         launches_per_step = per_gpu // chunk
         bytes_per_launch = (4 * n + 16) * chunk  # frame in, one 16-byte SpectrumPeak out
-        kernel_name = kernel_label = "spectrum_packed_kernel<float, 13, true, true, true>"
+        kernel_name = kernel_label = "spectrum_split16k_kernel<float, true, true>"
         plan.window("hann")
 
         def step():
@@ -242,7 +242,7 @@ def main() -> int:
         amp = torch.empty((chunk, bins), dtype=torch.float32, device=dev)
         launches_per_step = per_gpu // chunk
         bytes_per_launch = (4 * n + 4 * bins) * chunk  # 98,308 B per frame
-        kernel_name = kernel_label = "spectrum_packed_kernel<float, 13, true, true, false>"
+        kernel_name = kernel_label = "spectrum_split16k_kernel<float, true, false>"
         plan.window("hann")
 
         def step():
