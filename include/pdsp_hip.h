@@ -96,6 +96,10 @@ PDSP_API int pdsp_max_size(int scalar_bytes);
  * runs whole aligned one-sided N = 16384 f32 spectra on spectrum_split16k_kernel (two 4096-point
  * sub-transforms per workgroup); 0 on spectrum_packed_kernel<13>.  Same results within rounding. */
 PDSP_API int pdsp_set_split16k(int enabled);
+/* Same kind of switch for 32 <= N <= 256 transforms on 16-byte aligned planes: 1 (default) =
+ * fft_staged_kernel (the workgroup's contiguous 4096-point chunk staged through LDS with coalesced
+ * 16-byte accesses), 0 = the direct kernel. */
+PDSP_API int pdsp_set_staged_small(int enabled);
 
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).
  *   64 (default): f64 on the device for every size up to 2^17 -- the drop-in then meets the

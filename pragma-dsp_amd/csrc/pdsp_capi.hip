@@ -23,8 +23,10 @@
 namespace {
 
 thread_local std::string g_err;
-// development switch (tools / tests): 0 routes N = 16384 spectra to spectrum_packed_kernel<13>
+// development switches (tools / tests): 0 routes N = 16384 spectra to spectrum_packed_kernel<13>,
+// and 32 <= N <= 256 transforms to the direct kernel instead of fft_staged_kernel
 int g_split16k = 1;
+int g_staged_small = 1;
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -313,6 +315,32 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   }
   hipError_t e;
   pdsp::StoreComplex<T> st{re_out, im_out, plan->n, scale};
+  if (plan->log2n >= 5 && plan->log2n <= 8 && g_staged_small &&
+      (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & (4 * sizeof(T) - 1)) == 0) {
+    // small N: coalesced 16-byte I/O staged through LDS (fft_staged_kernel)
+    const long long blocks = (batch * plan->n + 4095) / 4096;
+#define PDSP_STAGED(L)                                                                                         \
+  do {                                                                                                         \
+    if (im_in) {                                                                                               \
+      pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};                                                          \
+      hipLaunchKernelGGL((pdsp::fft_staged_kernel<T, L, pdsp::LoadComplex<T>, pdsp::StoreComplex<T>>),          \
+                         dim3((unsigned)blocks), dim3(256), 0, s, ld, st, t.tw, batch);                        \
+    } else {                                                                                                   \
+      pdsp::LoadReal<T> ld{re_in, plan->n};                                                                    \
+      hipLaunchKernelGGL((pdsp::fft_staged_kernel<T, L, pdsp::LoadReal<T>, pdsp::StoreComplex<T>>),             \
+                         dim3((unsigned)blocks), dim3(256), 0, s, ld, st, t.tw, batch);                        \
+    }                                                                                                          \
+  } while (0)
+    switch (plan->log2n) {
+      case 5: PDSP_STAGED(5); break;
+      case 6: PDSP_STAGED(6); break;
+      case 7: PDSP_STAGED(7); break;
+      default: PDSP_STAGED(8); break;
+    }
+#undef PDSP_STAGED
+    PDSP_HIP_TRY(hipGetLastError());
+    return PDSP_OK;
+  }
   if (im_in) {
     pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};
     e = launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s);
@@ -751,6 +779,12 @@ int pdsp_max_size(int scalar_bytes) {  // incl. the four-step path
 int pdsp_set_split16k(int enabled) {
   const int prev = g_split16k;
   g_split16k = enabled ? 1 : 0;
+  return prev;
+}
+
+int pdsp_set_staged_small(int enabled) {
+  const int prev = g_staged_small;
+  g_staged_small = enabled ? 1 : 0;
   return prev;
 }
 

@@ -222,6 +222,10 @@ struct LoadComplex {  // forwardComplex / inverse (planes swapped by the caller)
     const size_t o = (size_t)row * (size_t)n + (size_t)off;
     return cx<T>{ld_stream(re + o + (unsigned)lane), ld_stream(im + o + (unsigned)lane)};
   }
+  static constexpr bool kPlanar = true;  // rows are contiguous planes: eligible for staged I/O
+  static constexpr bool kHasIm = true;
+  __device__ __forceinline__ const T *plane_re() const { return re; }
+  __device__ __forceinline__ const T *plane_im() const { return im; }
 };
 
 template <typename T>
@@ -231,6 +235,10 @@ struct LoadReal {  // Radix2Fft.forward: imaginary part is zero
   __device__ __forceinline__ cx<T> operator()(long long row, int off, int lane) const {
     return cx<T>{ld_stream(re + (size_t)row * (size_t)n + (size_t)off + (unsigned)lane), T(0)};
   }
+  static constexpr bool kPlanar = true;
+  static constexpr bool kHasIm = false;
+  __device__ __forceinline__ const T *plane_re() const { return re; }
+  __device__ __forceinline__ const T *plane_im() const { return nullptr; }
 };
 
 // Loads are unconditional (clamped address + select): a per-element `if` around a
@@ -263,6 +271,7 @@ struct StoreComplex {
     st_stream(v.x, re + o + (unsigned)lane);
     st_stream(v.y, im + o + (unsigned)lane);
   }
+  static constexpr bool kPlanar = true;
 };
 
 template <typename T>
@@ -507,6 +516,69 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
   if (live) {
     static_for<E>([&](auto q) { st(row, TP * q, tid, x[q]); });
   }
+}
+
+// Small transforms (32 <= N <= 256): only N/16 <= 16 threads own a row, so the direct kernel's
+// wave-level loads are 16..64-byte fragments of many rows (N = 64 measured 15 % of the HBM
+// roofline).  But the 4096/N rows of a workgroup are ONE contiguous 4096-point chunk per plane:
+// stage it through LDS with perfectly coalesced 16-byte accesses on both sides -- one extra LDS
+// round trip each way, cheap next to the few passes such a size needs.
+//   LD/ST must be the planar policies (kPlanar) over 16-byte aligned planes.
+template <typename T, int LOG2N, class LD, class ST>
+__global__ void __launch_bounds__(256)
+fft_staged_kernel(const LD ld, const ST st, const typename vec2<T>::type *__restrict__ tw, const long long batch) {
+  using TR = FftTraits<LOG2N>;
+  constexpr int N = TR::N, E = TR::E, TP = TR::TP, ROWS = TR::ROWS, WG = 256;
+  static_assert(TR::WG == WG && TR::NP > 1 && N % 16 == 0, "staged path: 32 <= N <= 256");
+  constexpr int CHUNK = ROWS * N;  // 4096 points per plane
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[TR::LDS_ELEMS];
+
+  const int t = (int)threadIdx.x;
+  const int tid = t % TP, rloc = t / TP;
+  cx<T> *const lrow = lds + rloc * TR::LROW;
+  const size_t base = (size_t)blockIdx.x * CHUNK;
+  const size_t limit = (size_t)batch * N;  // points per plane; a multiple of 4
+  const T *const pre = ld.plane_re();
+  const T *const pim = ld.plane_im();
+
+  // chunk -> LDS in natural order: point p of the chunk is element p % N of local row p / N
+  static_for<CHUNK / 4 / WG>([&](auto ic) {
+    const int p = 4 * (t + WG * ic);
+    size_t g = base + (size_t)p;
+    g = g + 4 <= limit ? g : limit - 4;  // the tail workgroup re-reads valid points; its dead rows never store
+    const V4 r = ld_stream(reinterpret_cast<const V4 *>(pre + g));
+    V4 m = V4{T(0), T(0), T(0), T(0)};
+    if constexpr (LD::kHasIm) m = ld_stream(reinterpret_cast<const V4 *>(pim + g));  // no run-time branch around a load
+    cx<T> *const d = lds + (p / N) * TR::LROW + lds_pad(p % N);  // 4 points never straddle a 16-block
+    d[0] = cx<T>{r.x, m.x};
+    d[1] = cx<T>{r.y, m.y};
+    d[2] = cx<T>{r.z, m.z};
+    d[3] = cx<T>{r.w, m.w};
+  });
+  __syncthreads();
+  cx<T> x[E];
+  {
+    const cx<T> *const rbase = lrow + lds_pad(tid);
+    static_for<E>([&](auto q) { x[q] = rbase[cpad(TP * q)]; });
+  }
+  __syncthreads();  // the first pass scatters into the same buffer
+
+  RegTwiddles<T, LOG2N> twf;
+  twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  fft_passes<T, LOG2N, true>(x, lrow, twf, tid);  // result in LDS, natural order per row
+  __syncthreads();
+
+  static_for<CHUNK / 4 / WG>([&](auto ic) {
+    const int p = 4 * (t + WG * ic);
+    const size_t g = base + (size_t)p;
+    if (g + 4 <= limit) {
+      const cx<T> *const d = lds + (p / N) * TR::LROW + lds_pad(p % N);
+      const cx<T> v0 = d[0] * st.scale, v1 = d[1] * st.scale, v2 = d[2] * st.scale, v3 = d[3] * st.scale;
+      st_stream(V4{v0.x, v1.x, v2.x, v3.x}, reinterpret_cast<V4 *>(st.re + g));
+      st_stream(V4{v0.y, v1.y, v2.y, v3.y}, reinterpret_cast<V4 *>(st.im + g));
+    }
+  });
 }
 
 // Fused body of spectrum() for real frames, one frame per row, via the packed-real

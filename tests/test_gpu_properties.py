@@ -134,3 +134,44 @@ def test_error_paths_on_device(pdsp):
     assert pdsp.lib.pdsp_plan_cache_clear() == 0
     r = pdsp.spectrum([], {"sampleRate": 8})  # nextPowerOfTwo(0) = 1
     assert len(r.amplitude) == 1 and r.amplitude[0] == 0 and r.peak.index == 0
+
+
+@pytest.mark.parametrize("n", [32, 64, 128, 256])
+@pytest.mark.parametrize("batch", [1, 3, 127, 128, 129, 1000])
+def test_staged_small_n_kernel_vs_direct_vs_oracle(pdsp, oracle_mod, n, batch):
+    """32 <= N <= 256 runs on fft_staged_kernel (coalesced 16-byte I/O staged through LDS);
+    pdsp_set_staged_small(0) routes the same call to the direct kernel."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    rng = np.random.default_rng(n + batch)
+    re = rng.standard_normal((batch, n)).astype(np.float32)
+    im = rng.standard_normal((batch, n)).astype(np.float32)
+    plan = BatchedFft(n, "cuda:0")
+    dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    rre, rim = oracle_mod.Plan(n).forward(re)
+    out = {}
+    for mode in (1, 0):
+        prev = pdsp.lib.pdsp_set_staged_small(mode)
+        try:
+            guard = torch.full((batch + 2, n), 777.0, device="cuda")
+            ore, oim = guard[1:batch + 1], torch.empty((batch, n), device="cuda")
+            plan.forward(dre, dim, out=(ore, oim))
+            r2, i2 = plan.forward(dre)
+            b1, b2 = plan.inverse(ore, oim)
+            torch.cuda.synchronize()
+        finally:
+            pdsp.lib.pdsp_set_staged_small(prev)
+        assert bool((guard[0] == 777.0).all()) and bool((guard[-1] == 777.0).all())
+        got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
+        assert rel_err(got, wre + 1j * wim) <= TOL
+        assert rel_err(r2.cpu().numpy().astype(np.float64) + 1j * i2.cpu().numpy(), rre + 1j * rim) <= TOL
+        assert rel_err(b1.cpu().numpy(), re) <= TOL and rel_err(b2.cpu().numpy(), im) <= TOL
+        out[mode] = got
+    assert rel_err(out[1], out[0]) <= 2e-6
+    # an unaligned view (4-byte offset) must fall back to the direct kernel and still be right
+    flat = torch.zeros(batch * n + 1, device="cuda")
+    view = flat[1:].view(batch, n)
+    view.copy_(dre)
+    u1, u2 = plan.forward(view, dim)
+    assert rel_err(u1.cpu().numpy().astype(np.float64) + 1j * u2.cpu().numpy(), wre + 1j * wim) <= TOL

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Size sweep on the GPU box: algorithmic GB/s of the C2C kernel and of the fused one-sided spectrum
+for N = 64 .. 16384 (about 1 GiB of input per launch).  Development tool."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pragma_dsp_amd.batch import BatchedFft
+
+dev = torch.device("cuda", 0)
+print(f"{'N':>6} {'C2C GB/s':>10} {'frac':>6} {'real GB/s':>10} {'frac':>6} {'spec GB/s':>10} {'frac':>6}")
+for log2n in range(6, 15):
+    n = 1 << log2n
+    batch = (1 << 27) // n  # 2^27 complex points: 1 GiB in + 1 GiB out for C2C
+    plan = BatchedFft(n, dev)
+    re = torch.randn((batch, n), device=dev)
+    im = torch.randn((batch, n), device=dev)
+    ore, oim = torch.empty_like(re), torch.empty_like(im)
+    amp = torch.empty((batch, n // 2 + 1), device=dev)
+    plan.window("hann")
+
+    def timed(fn, iters=20):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    t_c = timed(lambda: plan.forward(re, im, out=(ore, oim)))
+    t_r = timed(lambda: plan.forward(re, None, out=(ore, oim)))
+    t_s = timed(lambda: plan.spectrum(re, "hann", "one", out=amp))
+    c = 16.0 * batch * n / t_c / 1e9
+    r = 12.0 * batch * n / t_r / 1e9
+    s = (4.0 * n + 4.0 * (n // 2 + 1)) * batch / t_s / 1e9
+    print(f"{n:6d} {c:10.0f} {c/8000:6.3f} {r:10.0f} {r/8000:6.3f} {s:10.0f} {s/8000:6.3f}", flush=True)
+    del re, im, ore, oim, amp, plan
