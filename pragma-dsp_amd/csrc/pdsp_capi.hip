@@ -237,7 +237,6 @@ int check_plan_batch(const pdsp_plan *plan, long long batch) {
 template <typename T>
 int fourstep_ab(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, const T *win,
                 long long in_stride, long long frame_len, T *s_re, T *s_im, hipStream_t s) {
-  using T2 = typename pdsp::vec2<T>::type;
   const Tables<T> &t = tables<T>(plan);
   const int n2 = 1 << t.log2n2;
   const long long blocks = batch * (n2 / 256);
@@ -267,7 +266,6 @@ int fourstep_ab(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   pdsp::LoadComplex<T> ld{s_re, s_im, n2};
   pdsp::StoreComplex<T> st{s_re, s_im, n2, T(1)};
   PDSP_HIP_TRY(launch_fft<T>(t.log2n2, ld, st, t.tw, batch << t.log2n1, s));
-  (void)sizeof(T2);
   return PDSP_OK;
 }
 

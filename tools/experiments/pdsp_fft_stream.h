@@ -1,4 +1,8 @@
-// EXPERIMENT, NOT PRODUCT (kept for tools/kbench and the record in DESIGN.md section 5):
+// EXPERIMENT, NOT PRODUCT -- a record, not a buildable file: it was written against the scalar
+// (re[], im[]) kernel API of commit "Non-temporal streaming accesses, scalar row bases ..." and
+// does not compile against the current vector (cx) headers.  What survived of it in the product:
+// RegTwiddles (register-resident twiddle bases), now inside pdsp_fft_kernel.h.
+// (DESIGN.md section 5 tells the story.)
 // built, parity-tested (67 GPU tests passed with it in the dispatch) and measured in round 1;
 // it equals the one-row-per-workgroup kernel within 0.5 % once that kernel got non-temporal
 // accesses, so the simpler kernel ships.
