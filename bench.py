@@ -69,7 +69,9 @@ def cpu_baseline(re_rows: np.ndarray, im_rows, n: int, target_s: float = 12.0):
     reps = max(1, int(target_s / (per * rows)))
     sec, chk = plan.time_forward(re_rows, im_rows, reps=reps)
     done = rows * reps
+    node = node_baseline(n, im_rows is not None)
     return {
+        **({"node": node} if node else {}),
         "value": done * n / sec / 1e9,
         "unit": "GSample/s",
         "cores": 1,
@@ -79,6 +81,25 @@ def cpu_baseline(re_rows: np.ndarray, im_rows, n: int, target_s: float = 12.0):
         "transforms_per_s": done / sec,
         "checksum": chk,
     }
+
+
+def node_baseline(n: int, complex_input: bool, seconds: float = 5.0):
+    """The same transform loop under V8 (oracle/pdsp_oracle.js, a Node-compatible restatement of
+    src/core/fft.ts: typed-array f64, one thread) -- SURVEY 8(d)'s "Node CPU path"."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None:
+        return None
+    try:
+        p = subprocess.run([node, os.path.join(ROOT, "oracle", "pdsp_oracle.js"), "time", str(n), "256", str(seconds)]
+                           + (["complex"] if complex_input else []), capture_output=True, text=True, timeout=120)
+        d = json.loads(p.stdout)
+        return {"value": d["transforms"] * n / d["seconds"] / 1e9, "unit": "GSample/s", "cores": 1,
+                "transforms_per_s": d["transforms"] / d["seconds"],
+                "sample": f"{d['transforms']} transforms of N={n} in {d['seconds']:.1f} s, node {d['node']}"}
+    except Exception as e:  # a reported extra, never fatal
+        return {"error": repr(e)}
 
 
 def traffic_from_profile(kernel_substr: str):

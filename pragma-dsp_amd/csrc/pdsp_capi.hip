@@ -595,6 +595,29 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     // fast variant: whole pair-aligned frames, one-sided, no phase rows (config 4's shape)
     const bool fast = ((uintptr_t)frames & kPairMask) == 0 && (frame_stride & 1) == 0 && used == n &&
                       sides == PDSP_SIDES_ONE && phase_out == nullptr;
+    // 64 <= N <= 512, amplitude only: contiguous frames staged in / amplitude rows staged out through LDS
+    if (fast && !peaks_out && !peak_idx_out && plan->log2n >= 6 && plan->log2n <= 9 && g_staged_small && frame_stride == n &&
+        ((uintptr_t)frames & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)window & (4 * sizeof(T) - 1)) == 0) {
+      const long long blocks = (batch * (n / 2) + 4095) / 4096;
+#define PDSP_SSTAGED(LM)                                                                                            \
+  do {                                                                                                              \
+    if (window)                                                                                                     \
+      hipLaunchKernelGGL((pdsp::spectrum_staged_kernel<T, LM, true>), dim3((unsigned)blocks), dim3(256), 0, stream,  \
+                         frames, window, t.tw_half, t.twr, amp_out, s_edge, s_mid, batch);                          \
+    else                                                                                                            \
+      hipLaunchKernelGGL((pdsp::spectrum_staged_kernel<T, LM, false>), dim3((unsigned)blocks), dim3(256), 0, stream, \
+                         frames, window, t.tw_half, t.twr, amp_out, s_edge, s_mid, batch);                          \
+  } while (0)
+      switch (plan->log2n - 1) {
+        case 5: PDSP_SSTAGED(5); break;
+        case 6: PDSP_SSTAGED(6); break;
+        case 7: PDSP_SSTAGED(7); break;
+        default: PDSP_SSTAGED(8); break;
+      }
+#undef PDSP_SSTAGED
+      PDSP_HIP_TRY(hipGetLastError());
+      return PDSP_OK;
+    }
     if constexpr (sizeof(T) == 4) {
       // N = 16384: two 4096-point sub-transforms per 256-thread workgroup (4 frames per CU instead of 2)
       if (fast && plan->log2n == 14 && g_split16k && ((uintptr_t)frames & 15) == 0 && (frame_stride & 3) == 0 &&

@@ -150,3 +150,37 @@ def test_split16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, wind
         assert np.array_equal(res[mode][0][np.arange(7), res[mode][1][:7]], res[mode][2][:7])
     assert rel_err(res[1][0][:7], res[0][0][:7]) <= 2e-6          # the two kernels agree to rounding
     assert np.abs(((res[1][3][:7] - res[0][3][:7]) + np.pi) % (2 * np.pi) - np.pi).max() < 1e-4
+
+
+@pytest.mark.parametrize("n,batch", [(64, 1), (64, 128), (64, 131), (128, 64), (128, 77), (256, 33), (512, 16),
+                                     (512, 19), (512, 1), (256, 4099), (1024, 9)])
+@pytest.mark.parametrize("window", ["rect", "blackman"])
+def test_staged_small_spectrum_vs_packed_vs_oracle(pdsp, oracle_mod, n, batch, window):
+    """64 <= N <= 512, whole aligned frames, one-sided amplitude only: spectrum_staged_kernel (frames
+    staged in / amplitude rows staged out through LDS).  pdsp_set_staged_small(0) routes the same call
+    to spectrum_packed_kernel.  Batches that do not fill the last workgroup exercise the tail clamp;
+    the guard cells behind the output must stay untouched."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    rng = np.random.default_rng(n * 7 + batch)
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    x[0] = 0.0
+    dx = torch.from_numpy(x).cuda()
+    plan = BatchedFft(n, "cuda:0")
+    win = oracle_mod.create_window(window, n).astype(np.float32) if window != "rect" else None
+    wamp, _, _ = oracle_mod.Plan(n).spectrum_batch(x, window=win)
+    res = {}
+    for mode in (1, 0):
+        prev = pdsp.lib.pdsp_set_staged_small(mode)
+        try:
+            buf = torch.full((batch * (n // 2 + 1) + 64,), -7.0, device="cuda")
+            out = buf[:batch * (n // 2 + 1)].view(batch, n // 2 + 1)
+            plan.spectrum(dx, window, "one", out=out)
+            torch.cuda.synchronize()
+        finally:
+            pdsp.lib.pdsp_set_staged_small(prev)
+        assert bool((buf[batch * (n // 2 + 1):] == -7.0).all())
+        res[mode] = out.cpu().numpy()
+        assert rel_err(res[mode], wamp) <= TOL
+        assert not res[mode][0].any()
+    assert rel_err(res[1], res[0]) <= 2e-6

@@ -224,3 +224,37 @@ def test_complex_ops_known_answers(oracle_mod):
     a = np.arange(6.0)
     r, i = oracle_mod.complex_op("add", a, -a, [1.0, 2.0], [10.0, 20.0])  # row broadcast, period 2
     assert list(r) == [1, 3, 3, 5, 5, 7] and list(i) == [10, 19, 8, 17, 6, 15]
+
+
+# ---- oracle/pdsp_oracle.js: the "Node CPU path" timed by bench.py, pinned on the same goldens ----
+
+def _node_fft(cases):
+    import json, os, shutil, subprocess
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    req = {"cases": [{"n": len(c["re"]), "re": list(map(float, c["re"])),
+                      "im": None if c.get("im") is None else list(map(float, c["im"])),
+                      "inverse": bool(c.get("inverse"))} for c in cases]}
+    p = subprocess.run([node, os.path.join(root, "oracle", "pdsp_oracle.js"), "fft"], input=json.dumps(req),
+                       capture_output=True, text=True, timeout=120, check=True)
+    return [(np.array(r["re"]), np.array(r["im"])) for r in json.loads(p.stdout)["results"]]
+
+
+def test_node_oracle_matches_goldens_and_c_oracle(oracle_mod, reallife, v01, manifest):
+    names = [c["name"] for c in manifest["reallife"] if c["name"] not in ("large_amplitude", "tiny_amplitude")]
+    got = _node_fft([{"re": reallife[n + "/signal"]} for n in names])
+    for n, (re, im) in zip(names, got):  # signals.test.ts:22-23
+        assert np.abs(re - reallife[n + "/fftRe"]).max() < 1e-10, n
+        assert np.abs(im - reallife[n + "/fftIm"]).max() < 1e-10, n
+    # complex input and inverse: against the C oracle (same stage order => agreement to rounding)
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 8, 64, 4096):
+        z = rng.standard_normal((2, n))
+        (fre, fim), (bre, bim) = _node_fft([{"re": z[0], "im": z[1]}, {"re": z[0], "im": z[1], "inverse": True}])
+        plan = oracle_mod.Plan(n)
+        wre, wim = plan.forward_complex(z[0], z[1])
+        assert max(np.abs(fre - wre).max(), np.abs(fim - wim).max()) < 1e-12 * n
+        wre, wim = plan.inverse(z[0], z[1])
+        assert max(np.abs(bre - wre).max(), np.abs(bim - wim).max()) < 1e-14

@@ -5,9 +5,10 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pragma_dsp_amd.batch import BatchedFft
+from pragma_dsp_amd import _capi
 
 dev = torch.device("cuda", 0)
-print(f"{'N':>6} {'C2C GB/s':>10} {'frac':>6} {'real GB/s':>10} {'frac':>6} {'spec GB/s':>10} {'frac':>6}")
+print(f"{'N':>6} {'C2C GB/s':>10} {'frac':>6} {'real GB/s':>10} {'frac':>6} {'spec GB/s':>10} {'frac':>6} {'spec(direct)':>12}")
 for log2n in range(6, 15):
     n = 1 << log2n
     batch = (1 << 27) // n  # 2^27 complex points: 1 GiB in + 1 GiB out for C2C
@@ -33,8 +34,11 @@ for log2n in range(6, 15):
     t_c = timed(lambda: plan.forward(re, im, out=(ore, oim)))
     t_r = timed(lambda: plan.forward(re, None, out=(ore, oim)))
     t_s = timed(lambda: plan.spectrum(re, "hann", "one", out=amp))
+    prev = _capi.lib.pdsp_set_staged_small(0)
+    t_s0 = timed(lambda: plan.spectrum(re, "hann", "one", out=amp))
+    _capi.lib.pdsp_set_staged_small(prev)
     c = 16.0 * batch * n / t_c / 1e9
     r = 12.0 * batch * n / t_r / 1e9
     s = (4.0 * n + 4.0 * (n // 2 + 1)) * batch / t_s / 1e9
-    print(f"{n:6d} {c:10.0f} {c/8000:6.3f} {r:10.0f} {r/8000:6.3f} {s:10.0f} {s/8000:6.3f}", flush=True)
+    print(f"{n:6d} {c:10.0f} {c/8000:6.3f} {r:10.0f} {r/8000:6.3f} {s:10.0f} {s/8000:6.3f} {s*t_s/t_s0:12.0f}", flush=True)
     del re, im, ore, oim, amp, plan
