@@ -78,7 +78,8 @@ struct Tables {
   // split twiddles W_N^k, 0 <= k <= N/4
   T2 *tw_half = nullptr;
   T2 *twr = nullptr;
-  T2 *tw12 = nullptr;  // N = 16384 only: radix table of the 4096-point sub-transforms (split kernel)
+  T2 *tw12 = nullptr;  // N = 16384 only: radix table of the 4096-point sub-transforms (split kernels)
+  T2 *tws4 = nullptr;  // rows of 16384 points (log2n2 == 14): W_16384^k, k < 768 (fft_split4_kernel)
   T *win[4] = {nullptr, nullptr, nullptr, nullptr};  // createWindow(type, N), built on first use
   // four-step path (N beyond the single-pass limit): `tw` then belongs to the N2-point rows,
   // N1 = N / N2, and W_N^m = twa[m >> 9] * twb[m & 511]
@@ -89,6 +90,8 @@ struct Tables {
   void release() {
     if (tw12) (void)hipFree(tw12);
     tw12 = nullptr;
+    if (tws4) (void)hipFree(tws4);
+    tws4 = nullptr;
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
     twa = twb = nullptr;
@@ -180,6 +183,22 @@ hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const typename pdsp
   }
 }
 
+// Rows of planar complex points: N = 16384 (f32) goes to fft_split4_kernel when the input planes
+// allow 16-byte loads, everything else to the single-pass kernel of its size.
+template <typename T, class LD, class ST>
+hipError_t launch_rows(const Tables<T> &t, int log2n, const LD &ld, const ST &st, long long batch, hipStream_t s,
+                       bool aligned16) {
+  if constexpr (sizeof(T) == 4) {
+    if (log2n == 14 && g_split16k && aligned16 && t.tws4 && t.tw12) {
+      hipLaunchKernelGGL((pdsp::fft_split4_kernel<T, LD, ST>), dim3((unsigned)batch), dim3(256), 0, s, ld, st, t.tw12,
+                         t.tws4, batch);
+      return hipGetLastError();
+    }
+  }
+  return launch_fft<T>(log2n, ld, st, t.tw, batch, s);
+}
+
+
 template <typename T, int LOG2M>
 hipError_t launch_packed_one(bool fast, const T *frames, const T *win, long long frame_len, long long stride,
                              const typename pdsp::vec2<T>::type *tw, const typename pdsp::vec2<T>::type *twr, T *amp,
@@ -265,7 +284,7 @@ int fourstep_ab(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   // pass B: the N1 * batch rows of N2 points, in place (each workgroup loads its row before it stores)
   pdsp::LoadComplex<T> ld{s_re, s_im, n2};
   pdsp::StoreComplex<T> st{s_re, s_im, n2, T(1)};
-  PDSP_HIP_TRY(launch_fft<T>(t.log2n2, ld, st, t.tw, batch << t.log2n1, s));
+  PDSP_HIP_TRY(launch_rows<T>(t, t.log2n2, ld, st, batch << t.log2n1, s, true));  // scratch planes are aligned
   return PDSP_OK;
 }
 
@@ -339,12 +358,13 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
     PDSP_HIP_TRY(hipGetLastError());
     return PDSP_OK;
   }
+  const bool aligned16 = (((uintptr_t)re_in | (uintptr_t)im_in) & 15) == 0;
   if (im_in) {
     pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};
-    e = launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s);
+    e = launch_rows<T>(t, plan->log2n, ld, st, batch, s, aligned16);
   } else {
     pdsp::LoadReal<T> ld{re_in, plan->n};
-    e = launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s);
+    e = launch_rows<T>(t, plan->log2n, ld, st, batch, s, aligned16);
   }
   PDSP_HIP_TRY(e);
   return PDSP_OK;
@@ -467,6 +487,19 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
     const std::vector<T2> tw = build_twiddles<T2>(t.log2n2);
     e = hipMalloc((void **)&t.tw, tw.size() * sizeof(T2));
     if (e == hipSuccess) e = hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(T2), hipMemcpyHostToDevice);
+    if (e == hipSuccess && t.log2n2 == 14) {  // fft_split4_kernel: 4096-point radix table + W_16384^k
+      const std::vector<T2> t12 = build_twiddles<T2>(12);
+      std::vector<T2> w(768);
+      for (size_t k = 0; k < w.size(); ++k) {
+        const double angle = (-2.0 * M_PI * (double)k) / 16384.0;
+        w[k].x = (T)std::cos(angle);
+        w[k].y = (T)std::sin(angle);
+      }
+      e = hipMalloc((void **)&t.tw12, t12.size() * sizeof(T2));
+      if (e == hipSuccess) e = hipMemcpy(t.tw12, t12.data(), t12.size() * sizeof(T2), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc((void **)&t.tws4, w.size() * sizeof(T2));
+      if (e == hipSuccess) e = hipMemcpy(t.tws4, w.data(), w.size() * sizeof(T2), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && t.log2n1 > 0) {  // W_N^m = twa[m >> 9] * twb[m & 511]
       std::vector<T2> a((size_t)(size >> 9)), b(512);
       for (size_t i = 0; i < a.size(); ++i) {
@@ -497,7 +530,7 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
     if (e == hipSuccess) e = hipMemcpy(t.tw_half, twh.data(), twh.size() * sizeof(T2), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&t.twr, twr.size() * sizeof(T2));
     if (e == hipSuccess) e = hipMemcpy(t.twr, twr.data(), twr.size() * sizeof(T2), hipMemcpyHostToDevice);
-    if (e == hipSuccess && log2n == 14) {
+    if (e == hipSuccess && log2n == 14 && !t.tw12) {
       const std::vector<T2> t12 = build_twiddles<T2>(12);
       e = hipMalloc((void **)&t.tw12, t12.size() * sizeof(T2));
       if (e == hipSuccess) e = hipMemcpy(t.tw12, t12.data(), t12.size() * sizeof(T2), hipMemcpyHostToDevice);

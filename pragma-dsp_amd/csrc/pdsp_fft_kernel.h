@@ -323,8 +323,9 @@ __device__ __forceinline__ cx<T> mul_w32(const cx<T> a) {
                              0.19509032201612826785, 0.0};
     constexpr int q = m % 16;
     constexpr bool neg = m >= 16;
-    constexpr double cq = q <= 8 ? C[q] : -C[16 - q];
-    constexpr double sq = q <= 8 ? C[8 - q] : C[q - 8];
+    constexpr int lo = q <= 8 ? q : 16 - q;  // fold onto the first quarter turn
+    constexpr double cq = q <= 8 ? C[lo] : -C[lo];
+    constexpr double sq = C[8 - lo];
     constexpr T c = T(neg ? -cq : cq), s = T(neg ? sq : -sq);  // W = c + i*s
     return a.xx * cx<T>{c, s} + a.yy * cx<T>{-s, c};
   }
@@ -1023,11 +1024,13 @@ spectrum_staged_kernel(const T *__restrict__ frames, const T *__restrict__ win,
   });
 }
 
-// a * e^{-2*pi*i*NUM/64}, NUM compile-time (0 <= NUM < 16 is all the split kernel needs)
+// a * e^{-2*pi*i*NUM/64}, NUM compile-time
 template <typename T, int NUM>
 __device__ __forceinline__ cx<T> mul_w64(const cx<T> a) {
-  static_assert(NUM >= 0 && NUM < 32, "first half turn only");
-  if constexpr (NUM % 2 == 0) {
+  static_assert(NUM >= 0 && NUM < 64, "one turn");
+  if constexpr (NUM >= 32) {
+    return -mul_w64<T, NUM - 32>(a);
+  } else if constexpr (NUM % 2 == 0) {
     return mul_w32<T, NUM / 2>(a);
   } else {
     // cos(pi*j/32), j = 0..16
@@ -1038,11 +1041,85 @@ __device__ __forceinline__ cx<T> mul_w64(const cx<T> a) {
                               0.55557023301960222474, 0.47139673682599764856, 0.38268343236508977173,
                               0.29028467725446236764, 0.19509032201612826785, 0.09801714032956060199,
                               0.0};
-    constexpr double cq = NUM <= 16 ? C[NUM] : -C[32 - NUM];
-    constexpr double sq = NUM <= 16 ? C[16 - NUM] : C[NUM - 16];
+    constexpr int lo = NUM <= 16 ? NUM : 32 - NUM;  // fold onto the first quarter turn
+    constexpr double cq = NUM <= 16 ? C[lo] : -C[lo];
+    constexpr double sq = C[16 - lo];
     constexpr T c = T(cq), s = T(-sq);  // W = cos - i sin
     return a.xx * cx<T>{c, s} + a.yy * cx<T>{-s, c};
   }
+}
+
+// forward / forwardComplex / inverse at N = 16384 (f32), re-cut so that TWO workgroups fit a CU.
+// fft_stockham_kernel<14> needs 139 KB of LDS: one 1024-thread workgroup per CU whose load, compute
+// and store phases cannot overlap anything (52 % of the HBM roofline, against 77 % at N = 4096).
+// Here the transform is one radix-4 decimation-in-time step over four 4096-point transforms that
+// the SAME 256 threads run back to back through one 4096-point LDS buffer:
+//   one 16-byte load per plane gives x[4m..4m+3] = (s0[m], s1[m], s2[m], s3[m]);  Fj = FFT_4096(sj);
+//   X[k + 4096q] = sum_j (-i)^{jq} W_16384^{jk} Fj[k]   in registers (thread tid holds k = tid + 256e
+//   of all four).
+// 34.8 KB of LDS and ~200 VGPRs per thread: two workgroups per CU, 16-byte loads, and one
+// workgroup's HBM phases overlap the other's butterflies.
+//   tw12 = radix table of the 4096-point transform; tws[k] = W_16384^k, k < 768.
+template <typename T, class LD, class ST>
+__global__ void __launch_bounds__(256, 2)
+fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__restrict__ tw12,
+                  const typename vec2<T>::type *__restrict__ tws, const long long batch) {
+  using TR = FftTraits<12>;
+  constexpr int E = 16, TP = 256, H = 4096, N = 16384;
+  static_assert(LD::kPlanar && ST::kPlanar, "planar rows");
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[TR::LROW];
+
+  const int tid = (int)threadIdx.x;
+  const long long row = uniform_row<TP>((long long)blockIdx.x);
+  if (row >= batch) return;
+
+  const V4 *const r4 = reinterpret_cast<const V4 *>(ld.plane_re() + (size_t)row * N);
+  cx<T> a[E], b[E], c[E], d[E];
+  if constexpr (LD::kHasIm) {
+    const V4 *const i4 = reinterpret_cast<const V4 *>(ld.plane_im() + (size_t)row * N);
+    static_for<E>([&](auto q) {
+      const V4 r = ld_stream(r4 + TP * q + (unsigned)tid);
+      const V4 m = ld_stream(i4 + TP * q + (unsigned)tid);
+      a[q] = cx<T>{r.x, m.x};
+      b[q] = cx<T>{r.y, m.y};
+      c[q] = cx<T>{r.z, m.z};
+      d[q] = cx<T>{r.w, m.w};
+    });
+  } else {
+    static_for<E>([&](auto q) {
+      const V4 r = ld_stream(r4 + TP * q + (unsigned)tid);
+      a[q] = cx<T>{r.x, T(0)};
+      b[q] = cx<T>{r.y, T(0)};
+      c[q] = cx<T>{r.z, T(0)};
+      d[q] = cx<T>{r.w, T(0)};
+    });
+  }
+  RegTwiddles<T, 12> twf;
+  twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
+  const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
+  const cx<T> w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
+
+  fft_passes<T, 12, false>(a, lds, twf, tid);  // a[e] = F0[tid + 256e]
+  __syncthreads();                            // the buffer is reused by the next transform
+  fft_passes<T, 12, false>(b, lds, twf, tid);
+  __syncthreads();
+  fft_passes<T, 12, false>(c, lds, twf, tid);
+  __syncthreads();
+  fft_passes<T, 12, false>(d, lds, twf, tid);
+
+  // radix-4 combine; W_16384^{j(tid + 256e)} = wj * W_64^{je}
+  static_for<E>([&](auto ec) {
+    constexpr int e = ec;
+    const cx<T> t1 = cmul(b[e], mul_w64<T, e>(w1));
+    const cx<T> t2 = cmul(c[e], mul_w64<T, (2 * e) % 64>(w2));
+    const cx<T> t3 = cmul(d[e], mul_w64<T, (3 * e) % 64>(w3));
+    const cx<T> s0 = a[e] + t2, s1 = a[e] - t2, s2 = t1 + t3, s3 = mul_neg_i(t1 - t3);
+    st(row, 0 * H + TP * e, tid, s0 + s2);
+    st(row, 1 * H + TP * e, tid, s1 + s3);
+    st(row, 2 * H + TP * e, tid, s0 - s2);
+    st(row, 3 * H + TP * e, tid, s1 - s3);
+  });
 }
 
 // spectrum() body for N = 16384 real frames, the config-4 shape (whole 16-byte-aligned frames,

@@ -175,3 +175,47 @@ def test_staged_small_n_kernel_vs_direct_vs_oracle(pdsp, oracle_mod, n, batch):
     view.copy_(dre)
     u1, u2 = plan.forward(view, dim)
     assert rel_err(u1.cpu().numpy().astype(np.float64) + 1j * u2.cpu().numpy(), wre + 1j * wim) <= TOL
+
+
+@pytest.mark.parametrize("batch", [1, 5])
+def test_split4_kernel_n16384_vs_single_pass_vs_oracle(pdsp, oracle_mod, batch):
+    """N = 16384 rows on 16-byte aligned planes run on fft_split4_kernel (four 4096-point
+    sub-transforms + a radix-4 combine in registers); pdsp_set_split16k(0), or a 4-byte aligned
+    view, routes the same call to fft_stockham_kernel<14>."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 16384
+    rng = np.random.default_rng(4 + batch)
+    re = rng.standard_normal((batch, n)).astype(np.float32)
+    im = rng.standard_normal((batch, n)).astype(np.float32)
+    re[0] = np.cos(2 * np.pi * 1234 * np.arange(n) / n)  # one exact bin: X[1234] = N/2 (+ i*0)
+    im[0] = 0
+    plan = BatchedFft(n, "cuda:0")
+    dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    rre, rim = oracle_mod.Plan(n).forward(re)
+    out = {}
+    for mode in (1, 0):
+        prev = pdsp.lib.pdsp_set_split16k(mode)
+        try:
+            guard = torch.full((batch + 2, n), 777.0, device="cuda")
+            ore, oim = guard[1:batch + 1], torch.empty((batch, n), device="cuda")
+            plan.forward(dre, dim, out=(ore, oim))
+            r2, i2 = plan.forward(dre)
+            b1, b2 = plan.inverse(ore, oim)
+            torch.cuda.synchronize()
+        finally:
+            pdsp.lib.pdsp_set_split16k(prev)
+        assert bool((guard[0] == 777.0).all()) and bool((guard[-1] == 777.0).all())
+        got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
+        assert rel_err(got, wre + 1j * wim) <= TOL
+        assert abs(got[0, 1234] - n / 2) < 1e-2 and abs(got[0, n - 1234] - n / 2) < 1e-2
+        assert rel_err(r2.cpu().numpy().astype(np.float64) + 1j * i2.cpu().numpy(), rre + 1j * rim) <= TOL
+        assert rel_err(b1.cpu().numpy(), re) <= TOL and rel_err(b2.cpu().numpy(), im) <= TOL
+        out[mode] = got
+    assert rel_err(out[1], out[0]) <= 2e-6
+    flat = torch.zeros(batch * n + 1, device="cuda")  # 4-byte aligned view: single-pass kernel
+    view = flat[1:].view(batch, n)
+    view.copy_(dre)
+    ure, uim = plan.forward(view, dim)
+    assert rel_err(ure.cpu().numpy().astype(np.float64) + 1j * uim.cpu().numpy(), wre + 1j * wim) <= TOL
