@@ -92,6 +92,7 @@ struct Tables {
     tw12 = nullptr;
     if (tws4) (void)hipFree(tws4);
     tws4 = nullptr;
+
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
     twa = twb = nullptr;
@@ -190,8 +191,8 @@ hipError_t launch_rows(const Tables<T> &t, int log2n, const LD &ld, const ST &st
                        bool aligned16) {
   if constexpr (sizeof(T) == 4) {
     if (log2n == 14 && g_split16k && aligned16 && t.tws4 && t.tw12) {
-      hipLaunchKernelGGL((pdsp::fft_split4_kernel<T, LD, ST>), dim3((unsigned)batch), dim3(256), 0, s, ld, st, t.tw12,
-                         t.tws4, batch);
+      hipLaunchKernelGGL((pdsp::fft_split4_kernel<T, 12, LD, ST>), dim3((unsigned)batch), dim3(256), 0, s, ld, st,
+                         t.tw12, t.tws4, batch);
       return hipGetLastError();
     }
   }

@@ -1060,13 +1060,14 @@ __device__ __forceinline__ cx<T> mul_w64(const cx<T> a) {
 // 34.8 KB of LDS and ~200 VGPRs per thread: two workgroups per CU, 16-byte loads, and one
 // workgroup's HBM phases overlap the other's butterflies.
 //   tw12 = radix table of the 4096-point transform; tws[k] = W_16384^k, k < 768.
-template <typename T, class LD, class ST>
-__global__ void __launch_bounds__(256, 2)
+template <typename T, int LOG2S, class LD, class ST>
+__global__ void __launch_bounds__((1 << LOG2S) / 16, 2)
 fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__restrict__ tw12,
                   const typename vec2<T>::type *__restrict__ tws, const long long batch) {
-  using TR = FftTraits<12>;
-  constexpr int E = 16, TP = 256, H = 4096, N = 16384;
+  using TR = FftTraits<LOG2S>;
+  constexpr int E = 16, TP = TR::TP, H = TR::N, N = 4 * H;
   static_assert(LD::kPlanar && ST::kPlanar, "planar rows");
+  static_assert(TP >= 64 && TP % 64 == 0, "whole waves per row");
   typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ cx<T> lds[TR::LROW];
 
@@ -1095,20 +1096,20 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
       d[q] = cx<T>{r.w, T(0)};
     });
   }
-  RegTwiddles<T, 12> twf;
+  RegTwiddles<T, LOG2S> twf;
   twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
   const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
   const cx<T> w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
 
-  fft_passes<T, 12, false>(a, lds, twf, tid);  // a[e] = F0[tid + 256e]
-  __syncthreads();                            // the buffer is reused by the next transform
-  fft_passes<T, 12, false>(b, lds, twf, tid);
+  fft_passes<T, LOG2S, false>(a, lds, twf, tid);  // a[e] = F0[tid + TP*e]
+  __syncthreads();                               // the buffer is reused by the next transform
+  fft_passes<T, LOG2S, false>(b, lds, twf, tid);
   __syncthreads();
-  fft_passes<T, 12, false>(c, lds, twf, tid);
+  fft_passes<T, LOG2S, false>(c, lds, twf, tid);
   __syncthreads();
-  fft_passes<T, 12, false>(d, lds, twf, tid);
+  fft_passes<T, LOG2S, false>(d, lds, twf, tid);
 
-  // radix-4 combine; W_16384^{j(tid + 256e)} = wj * W_64^{je}
+  // radix-4 combine; W_N^{j(tid + TP*e)} = wj * W_64^{je}  (N = 64*TP)
   static_for<E>([&](auto ec) {
     constexpr int e = ec;
     const cx<T> t1 = cmul(b[e], mul_w64<T, e>(w1));
