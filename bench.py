@@ -176,7 +176,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "spectrum16k", "peaks16k", "single1024"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,6 +213,10 @@ def main() -> int:
 
     if args.workload in ("spectrum16k", "peaks16k"):
         n, per_gpu = 16384, args.batch or (1 << 20)
+    elif args.workload == "fft16k":
+        n, per_gpu = 16384, args.batch or 16384  # 2^28 samples, as configs[2]
+    elif args.workload == "spectrum256":
+        n, per_gpu = 256, args.batch or (1 << 22)
     else:
         n, per_gpu = 4096, args.batch or 65536
     # weak scaling: the global batch is per_gpu x world rows, split contiguously by rank
@@ -222,12 +226,14 @@ def main() -> int:
     plan = BatchedFft(n, dev)
     stream = torch.cuda.current_stream(dev)
 
-    if args.workload == "fft4096":
+    if args.workload in ("fft4096", "fft16k"):
         re, im = synth_batch(per_gpu, n, dev, seed=1337 + rank)
         ore, oim = torch.empty_like(re), torch.empty_like(im)
         launches_per_step = 1
         bytes_per_launch = 16 * per_gpu * n  # 8 B read + 8 B written per sample
         kernel_name, kernel_label = "LoadComplex", "fft_stockham_kernel<float, 12, LoadComplex, StoreComplex>"
+        if args.workload == "fft16k":
+            kernel_name, kernel_label = "fft_split4", "fft_split4_kernel<float, 12, LoadComplex, StoreComplex>"
 
         def step():
             plan.forward(re, im, out=(ore, oim))
@@ -255,7 +261,7 @@ def main() -> int:
             for _ in range(launches_per_step):
                 plan.spectrum_peaks(re, "hann", "one", 48000.0)
     else:
-        chunk = min(args.chunk, per_gpu)
+        chunk = min(args.chunk if args.workload == "spectrum16k" else (1 << 20), per_gpu)  # ~1 GiB of frames per launch
         assert per_gpu % chunk == 0
         re, _ = synth_batch(chunk, n, dev, seed=1337 + rank, complex_noise=False)
         im = None
@@ -264,6 +270,8 @@ def main() -> int:
         launches_per_step = per_gpu // chunk
         bytes_per_launch = (4 * n + 4 * bins) * chunk  # 98,308 B per frame
         kernel_name = kernel_label = "spectrum_split16k_kernel<float, true, false>"
+        if args.workload == "spectrum256":
+            kernel_name = kernel_label = "spectrum_staged_kernel<float, 7, true>"
         plan.window("hann")
 
         def step():
@@ -342,6 +350,8 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": {"fft4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex (configs[2])",
                                     "real4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forward fp32 real input",
+                                    "fft16k": f"N=16384 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex",
+                                    "spectrum256": f"N=256 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude",
                                     "spectrum16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude (configs[3])",
                                     "peaks16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+findPeak, peaks-only output"}[args.workload],
                        "n": n, "batch_per_gpu": per_gpu, "global_batch": per_gpu * world,
