@@ -32,6 +32,17 @@
 
 #include "pdsp_radix.h"
 
+// Option: sub-transforms of the split kernels run pairwise through two LDS rows (fft_passes_pair:
+// shared barriers, read-backs in flight together).  Off: measured in the library on one box it is
+// slower for fft_split4_kernel (C2C 5.41 vs 5.94 TB/s, real-in 4.91 vs 5.81) and -1 % for
+// spectrum_split16k_kernel, although the standalone micro-benchmark had shown +3..5 %.
+#ifndef PDSP_SPLIT4_PAIRED
+#define PDSP_SPLIT4_PAIRED 0
+#endif
+#ifndef PDSP_SPLIT16K_PAIRED
+#define PDSP_SPLIT16K_PAIRED 0
+#endif
+
 namespace pdsp {
 
 // Diagnostic build only (tools/kbench -DPDSP_STAMPS): wave 0 of each workgroup adds the shader
@@ -388,6 +399,64 @@ struct RegTwiddles {
 
 // ---- the passes --------------------------------------------------------------
 
+// Pass p for one thread's E points: twiddle, radix-R butterflies, then either the autosort scatter
+// to LDS or (register-resident last pass) back into x in natural order.
+template <typename T, int LOG2N, bool LAST_TO_LDS, int LOG2E, int p, class TWF, int EE>
+__device__ __forceinline__ void fft_pass_compute(cx<T> (&x)[EE], cx<T> *const lrow, const TWF &twf, const int tid) {
+  using TR = FftTraits<LOG2N, LOG2E>;
+  constexpr int E = TR::E, TP = TR::TP, NP = TR::NP;
+  static_assert(EE == E, "register array size must be the plan's points per thread");
+  // For N >= 256 every LDS address is (a thread-only base) + (a compile-time offset),
+  // so there is one address register per pass instead of one per element.
+  constexpr bool kConstOffsets = (TP % 16 == 0);
+  constexpr int R = TR::P.r[p], Ns = TR::P.ns[p], EB = E / R, LR = ilog2(R);
+  constexpr bool last = (p == NP - 1);
+  constexpr bool to_lds = !last || LAST_TO_LDS;
+
+  static_for<EB>([&](auto bc) {
+    constexpr int b = bc;
+    cx<T> a[R];
+    static_for<R>([&](auto rc) { a[rc] = x[b + rc * EB]; });
+    const int j = tid + b * TP;  // butterfly index within the pass, 0 <= j < N/R
+    if constexpr (Ns > 1) {
+      static_for<R - 1>([&](auto rc) {
+        constexpr int r = rc + 1;
+        a[r] = cmul(a[r], twf.template get<p, r, b>(j));
+      });
+    }
+    fft_reg<T, R>(a);
+    if constexpr (!to_lds) {
+      // Ns*R == N: output r of butterfly j is X[j + r*N/R] = slot b + r*EB
+      static_for<R>([&](auto rc) { x[b + rc * EB] = a[bitrev(rc, LR)]; });
+    } else if constexpr (kConstOffsets) {
+      // autosort scatter (natural order when Ns*R == N).  j = tid + b*TP: the part of the
+      // index that depends on b and rc is the constant c = cb + rc*Ns, and
+      // pad(j0t + c) == pad(j0t) + cpad(c): cb is a multiple of 16, and (j0t & 15) + (rc*Ns & 15)
+      // never carries (for Ns < 16 the first is < Ns, the second a multiple of Ns below 16)
+      constexpr int cb = Ns <= TP ? b * TP * R : b * TP;
+      const int j0t = Ns <= TP ? ((tid >> ilog2(Ns)) << ilog2(Ns * R)) + (tid & (Ns - 1)) : tid;
+      cx<T> *const wbase = lrow + lds_pad(j0t);
+      static_for<R>([&](auto rc) { wbase[cpad(cb + rc * Ns)] = a[bitrev(rc, LR)]; });
+    } else {
+      const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
+      static_for<R>([&](auto rc) { lrow[lds_pad(j0 + rc * Ns)] = a[bitrev(rc, LR)]; });
+    }
+  });
+}
+
+// The thread's E inputs of the next pass, x[q] = row[tid + TP*q], after the barrier behind a scatter.
+template <typename T, int LOG2N, int LOG2E, int EE>
+__device__ __forceinline__ void fft_pass_readback(cx<T> (&x)[EE], const cx<T> *const lrow, const int tid) {
+  using TR = FftTraits<LOG2N, LOG2E>;
+  constexpr int E = TR::E, TP = TR::TP;
+  if constexpr (TP % 16 == 0) {
+    const cx<T> *const rbase = lrow + lds_pad(tid);
+    static_for<E>([&](auto q) { x[q] = rbase[cpad(TP * q)]; });
+  } else {
+    static_for<E>([&](auto q) { x[q] = lrow[lds_pad(tid + TP * q)]; });
+  }
+}
+
 // Runs every pass of the length-2^LOG2N transform on the E points each of the TP
 // cooperating threads holds.  LAST_TO_LDS = false: the result comes back in the
 // registers, X[tid + TP*q] in slot q.  LAST_TO_LDS = true: the last pass also
@@ -397,62 +466,38 @@ struct RegTwiddles {
 template <typename T, int LOG2N, bool LAST_TO_LDS, int LOG2E = 4, class TWF = void, int EE = 0>
 __device__ __forceinline__ void fft_passes(cx<T> (&x)[EE], cx<T> *const lrow, const TWF &twf, const int tid) {
   PDSP_STAMP_INIT();
-  using TR = FftTraits<LOG2N, LOG2E>;
-  constexpr int E = TR::E, TP = TR::TP, NP = TR::NP;
-  static_assert(EE == E, "register array size must be the plan's points per thread");
-  // For N >= 256 every LDS address is (a thread-only base) + (a compile-time offset),
-  // so there is one address register per pass instead of one per element.
-  constexpr bool kConstOffsets = (TP % 16 == 0);
-
+  constexpr int NP = FftTraits<LOG2N, LOG2E>::NP;
   static_for<NP>([&](auto pc) {
     constexpr int p = pc;
-    constexpr int R = TR::P.r[p], Ns = TR::P.ns[p], EB = E / R, LR = ilog2(R);
-    constexpr bool last = (p == NP - 1);
-    constexpr bool to_lds = !last || LAST_TO_LDS;
-
-    static_for<EB>([&](auto bc) {
-      constexpr int b = bc;
-      cx<T> a[R];
-      static_for<R>([&](auto rc) { a[rc] = x[b + rc * EB]; });
-      const int j = tid + b * TP;  // butterfly index within the pass, 0 <= j < N/R
-      if constexpr (Ns > 1) {
-        static_for<R - 1>([&](auto rc) {
-          constexpr int r = rc + 1;
-          a[r] = cmul(a[r], twf.template get<p, r, b>(j));
-        });
-      }
-      fft_reg<T, R>(a);
-      if constexpr (!to_lds) {
-        // Ns*R == N: output r of butterfly j is X[j + r*N/R] = slot b + r*EB
-        static_for<R>([&](auto rc) { x[b + rc * EB] = a[bitrev(rc, LR)]; });
-      } else if constexpr (kConstOffsets) {
-        // autosort scatter (natural order when Ns*R == N).  j = tid + b*TP: the part of the
-        // index that depends on b and rc is the constant c = cb + rc*Ns, and
-        // pad(j0t + c) == pad(j0t) + cpad(c): cb is a multiple of 16, and (j0t & 15) + (rc*Ns & 15)
-        // never carries (for Ns < 16 the first is < Ns, the second a multiple of Ns below 16)
-        constexpr int cb = Ns <= TP ? b * TP * R : b * TP;
-        const int j0t = Ns <= TP ? ((tid >> ilog2(Ns)) << ilog2(Ns * R)) + (tid & (Ns - 1)) : tid;
-        cx<T> *const wbase = lrow + lds_pad(j0t);
-        static_for<R>([&](auto rc) { wbase[cpad(cb + rc * Ns)] = a[bitrev(rc, LR)]; });
-      } else {
-        const int j0 = ((j >> ilog2(Ns)) << ilog2(Ns * R)) + (j & (Ns - 1));
-        static_for<R>([&](auto rc) { lrow[lds_pad(j0 + rc * Ns)] = a[bitrev(rc, LR)]; });
-      }
-    });
-
+    fft_pass_compute<T, LOG2N, LAST_TO_LDS, LOG2E, p>(x, lrow, twf, tid);
     PDSP_STAMP(8 + 4 * p);  // twiddle loads + butterflies + LDS scatter issued
-    if constexpr (!last) {
+    if constexpr (p != NP - 1) {
       __syncthreads();
       PDSP_STAMP(9 + 4 * p);  // barrier (incl. draining the scatter)
-      if constexpr (kConstOffsets) {
-        const cx<T> *const rbase = lrow + lds_pad(tid);
-        static_for<E>([&](auto q) { x[q] = rbase[cpad(TP * q)]; });
-      } else {
-        static_for<E>([&](auto q) { x[q] = lrow[lds_pad(tid + TP * q)]; });
-      }
+      fft_pass_readback<T, LOG2N, LOG2E>(x, lrow, tid);
       // the next pass writes LDS again (every pass but a register-resident last one)
       if constexpr (p + 1 < NP - 1 || LAST_TO_LDS) __syncthreads();
       PDSP_STAMP(10 + 4 * p);  // LDS read-back issued + barrier
+    }
+  });
+}
+
+// Two independent transforms of the same threads, pass by pass through two LDS rows: the pair
+// shares every barrier and its LDS read-backs are in flight together (half the exposed round
+// trips of running fft_passes twice).
+template <typename T, int LOG2N, bool LAST_TO_LDS, int LOG2E = 4, class TWF = void, int EE = 0>
+__device__ __forceinline__ void fft_passes_pair(cx<T> (&x0)[EE], cx<T> (&x1)[EE], cx<T> *const l0, cx<T> *const l1,
+                                                const TWF &twf, const int tid) {
+  constexpr int NP = FftTraits<LOG2N, LOG2E>::NP;
+  static_for<NP>([&](auto pc) {
+    constexpr int p = pc;
+    fft_pass_compute<T, LOG2N, LAST_TO_LDS, LOG2E, p>(x0, l0, twf, tid);
+    fft_pass_compute<T, LOG2N, LAST_TO_LDS, LOG2E, p>(x1, l1, twf, tid);
+    if constexpr (p != NP - 1) {
+      __syncthreads();
+      fft_pass_readback<T, LOG2N, LOG2E>(x0, l0, tid);
+      fft_pass_readback<T, LOG2N, LOG2E>(x1, l1, tid);
+      if constexpr (p + 1 < NP - 1 || LAST_TO_LDS) __syncthreads();
     }
   });
 }
@@ -1069,7 +1114,7 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   static_assert(LD::kPlanar && ST::kPlanar, "planar rows");
   static_assert(TP >= 64 && TP % 64 == 0, "whole waves per row");
   typedef T V4 __attribute__((ext_vector_type(4)));
-  __shared__ cx<T> lds[TR::LROW];
+  __shared__ cx<T> lds[(PDSP_SPLIT4_PAIRED ? 2 : 1) * TR::LROW];
 
   const int tid = (int)threadIdx.x;
   const long long row = uniform_row<TP>((long long)blockIdx.x);
@@ -1101,6 +1146,11 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
   const cx<T> w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
 
+#if PDSP_SPLIT4_PAIRED
+  fft_passes_pair<T, LOG2S, false>(a, b, lds, lds + TR::LROW, twf, tid);  // a[e] = F0[tid + TP*e], b[e] = F1[..]
+  __syncthreads();                                                       // the buffers are reused by the next pair
+  fft_passes_pair<T, LOG2S, false>(c, d, lds, lds + TR::LROW, twf, tid);
+#else
   fft_passes<T, LOG2S, false>(a, lds, twf, tid);  // a[e] = F0[tid + TP*e]
   __syncthreads();                               // the buffer is reused by the next transform
   fft_passes<T, LOG2S, false>(b, lds, twf, tid);
@@ -1108,6 +1158,7 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   fft_passes<T, LOG2S, false>(c, lds, twf, tid);
   __syncthreads();
   fft_passes<T, LOG2S, false>(d, lds, twf, tid);
+#endif
 
   // radix-4 combine; W_N^{j(tid + TP*e)} = wj * W_64^{je}  (N = 64*TP)
   static_for<E>([&](auto ec) {
@@ -1147,7 +1198,7 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
   using TR = FftTraits<12>;
   constexpr int E = 16, TP = 256, H = 4096, M = 8192;
   typedef T V4 __attribute__((ext_vector_type(4)));
-  __shared__ cx<T> lds[TR::LROW];
+  __shared__ cx<T> lds[(PDSP_SPLIT16K_PAIRED ? 2 : 1) * TR::LROW];
 
   const int tid = (int)threadIdx.x;
   const long long row = uniform_row<TP>((long long)blockIdx.x);
@@ -1177,9 +1228,21 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
     });
   }
 
+  PDSP_STAMP_INIT();
+#ifdef PDSP_STAMPS
+  pin_regs<T, E>(a);  // land the frame + window here
+  pin_regs<T, E>(b);
+#endif
+  PDSP_STAMP(32);  // wait for the frame + window loads
+#if PDSP_SPLIT16K_PAIRED
+  fft_passes_pair<T, 12, false>(a, b, lds, lds + TR::LROW, twf, tid);  // a[q] = Ev[tid + 256q], b[q] = Od[tid + 256q]
+#else
   fft_passes<T, 12, false>(a, lds, twf, tid);  // a[q] = Ev[tid + 256q]
   __syncthreads();                            // the buffer is reused by the second transform
+  PDSP_STAMP(33);  // first sub-transform
   fft_passes<T, 12, false>(b, lds, twf, tid);  // b[q] = Od[tid + 256q]
+#endif
+  PDSP_STAMP(34);  // second sub-transform
 
   // radix-2 combine in registers: a <- Z[k], b <- Z[k + 4096]
   static_for<E>([&](auto q) {
@@ -1194,6 +1257,7 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
     static_for<E>([&](auto q) { wbase[cpad(TP * q)] = b[q]; });
   }
   __syncthreads();
+  PDSP_STAMP(35);  // combine + upper half through LDS
 
   T *const arow = amp + (size_t)row * (size_t)(M + 1);
   const bool store_amp = !PEAK || amp != nullptr;
@@ -1239,6 +1303,7 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
     if constexpr (PEAK) best.consider(mm, H, xm);
     if (store_amp) st_rowtail(mm, arow + (unsigned)H);
   }
+  PDSP_STAMP(36);  // Hermitian split + magnitude + stores issued
 
   if constexpr (PEAK) {
     static_for<6>([&](auto sc) {

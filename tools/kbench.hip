@@ -105,6 +105,11 @@ static int spec_main(long long frames, int rounds) {
   CK(hipMemcpy(dtw12, tw12.data(), tw12.size() * 8, hipMemcpyHostToDevice));
   const bool split = getenv("KB_SPLIT") != nullptr;
   auto run = [&] {
+    if (split && getenv("KB_NOWIN")) {
+      hipLaunchKernelGGL((pdsp::spectrum_split16k_kernel<float, false, false>), dim3(frames), dim3(256), 0, 0, x, win,
+                         (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
+      return;
+    }
     if (split) {
       hipLaunchKernelGGL((pdsp::spectrum_split16k_kernel<float, true, false>), dim3(frames), dim3(256), 0, 0, x, win,
                          (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
@@ -138,6 +143,10 @@ static int spec_main(long long frames, int rounds) {
     double tot = 0;
     for (int i = 0; i < 3; ++i) tot += acc[i] / wgs;
     for (int i = 0; i < 3; ++i) printf("  %-14s %9.0f cycles/WG  %5.1f %%\n", names[i], acc[i] / wgs, 100.0 * acc[i] / wgs / tot);
+    if (split) {
+      const char *sn[] = {"wait frame+window", "sub-transform 1", "sub-transform 2", "combine+LDS", "split+mag+stores"};
+      for (int i = 0; i < 5; ++i) printf("  %-18s %9.0f cycles/WG\n", sn[i], acc[32 + i] / (double)frames);
+    }
     for (int p = 0; p < 5; ++p)
       if (acc[8 + 4 * p])
         printf("    pass %d: compute+scatter %8.0f   barrier %8.0f   readback+barrier %8.0f\n", p, acc[8 + 4 * p] / wgs,
@@ -146,11 +155,126 @@ static int spec_main(long long frames, int rounds) {
 #endif
   std::sort(ms.begin(), ms.end());
   const double bytes = (4.0 * n + 4.0 * bins) * frames;
-  printf("spectrum16k frames=%lld  med %.4f ms  min %.4f ms  med %.1f GB/s  max %.1f GB/s\n", frames, ms[ms.size() / 2], ms[0], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+  printf("spectrum16k paired=%d frames=%lld  med %.4f ms  min %.4f ms  med %.1f GB/s  max %.1f GB/s\n", PDSP_SPLIT16K_PAIRED, frames, ms[ms.size() / 2], ms[0], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+  return 0;
+}
+
+// N=16384 C2C rows on fft_split4_kernel (argv: rows rounds c16k)
+static int c16k_main(long long rows, int rounds) {
+  const int n = 16384;
+  const size_t cnt = (size_t)rows * n;
+  float *re, *im, *ore, *oim;
+  CK(hipMalloc(&re, cnt * 4));
+  CK(hipMalloc(&im, cnt * 4));
+  CK(hipMalloc(&ore, cnt * 4));
+  CK(hipMalloc(&oim, cnt * 4));
+  {
+    std::vector<float> h(cnt);
+    unsigned s = 4242;
+    for (auto &v : h) {
+      s = s * 1664525u + 1013904223u;
+      v = ((s >> 8) & 0xffff) / 32768.0f - 1.0f;
+    }
+    CK(hipMemcpy(re, h.data(), cnt * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(im, h.data() + 1, (cnt - 1) * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<float2> tw12, tws(768);
+  fill_tw(12, tw12);
+  for (int k = 0; k < 768; ++k) tws[k] = make_float2((float)cos(-2 * M_PI * k / n), (float)sin(-2 * M_PI * k / n));
+  float2 *dtw12, *dtws;
+  CK(hipMalloc(&dtw12, tw12.size() * 8));
+  CK(hipMemcpy(dtw12, tw12.data(), tw12.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dtws, tws.size() * 8));
+  CK(hipMemcpy(dtws, tws.data(), tws.size() * 8, hipMemcpyHostToDevice));
+  pdsp::LoadComplex<float> ld{re, im, n};
+  pdsp::StoreComplex<float> st{ore, oim, n, 1.0f};
+  auto run = [&] {
+    hipLaunchKernelGGL((pdsp::fft_split4_kernel<float, 12, decltype(ld), decltype(st)>), dim3(rows), dim3(256), 0, 0, ld,
+                       st, dtw12, dtws, rows);
+  };
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> ms;
+  for (int i = 0; i < 20; ++i) run();
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) run();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    ms.push_back(t / 5);
+  }
+  CK(hipGetLastError());
+  std::sort(ms.begin(), ms.end());
+  const double bytes = 16.0 * cnt;
+  printf("c2c16k rows=%lld paired=%d  med %.4f ms  min %.4f ms  med %.1f GB/s  max %.1f GB/s\n", rows, PDSP_SPLIT4_PAIRED,
+         ms[ms.size() / 2], ms[0], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+  return 0;
+}
+
+// HBM ceilings by read:write mix (argv: MiB rounds mix): float4 grid-stride kernels, non-temporal
+template <int R, int W>
+__global__ void __launch_bounds__(256) mix_kernel(const float4 *__restrict__ in_, float4 *__restrict__ out_, size_t n4) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  const V4 *in = reinterpret_cast<const V4 *>(in_);
+  V4 *out = reinterpret_cast<V4 *>(out_);
+  // each step reads R float4 (from R planes of n4) and writes W float4 (to W planes of n4)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    V4 acc = V4{0, 0, 0, 0};
+    for (int r = 0; r < R; ++r) acc += __builtin_nontemporal_load(in + (size_t)r * n4 + i);
+    if (W == 0) {
+      if (acc.x == 12345.678f) out[0] = acc;  // never true: keeps the loads alive
+    } else {
+      for (int w = 0; w < W; ++w) __builtin_nontemporal_store(acc, out + (size_t)w * n4 + i);
+    }
+  }
+}
+
+template <int R, int W>
+static void mix_run(const float4 *in, float4 *out, size_t n4, int rounds, int grid) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> ms;
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((mix_kernel<R, W>), dim3(grid), dim3(256), 0, 0, in, out, n4);
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((mix_kernel<R, W>), dim3(grid), dim3(256), 0, 0, in, out, n4);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    ms.push_back(t / 5);
+  }
+  std::sort(ms.begin(), ms.end());
+  const double bytes = 16.0 * n4 * (R + W);
+  printf("mix read:write %d:%d grid %5d  med %.4f ms  %.0f GB/s (max %.0f)\n", R, W, grid, ms[ms.size() / 2],
+         bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+}
+
+static int mix_main(long long mib, int rounds) {
+  const size_t n4 = (size_t)mib * 1024 * 1024 / 16;  // float4 per plane
+  float4 *in, *out;
+  CK(hipMalloc(&in, n4 * 16 * 4));
+  CK(hipMalloc(&out, n4 * 16 * 2));
+  CK(hipMemset(in, 0, n4 * 16 * 4));
+  for (int grid : {2048, 8192, 65536}) {
+    mix_run<1, 0>(in, out, n4 * 4, rounds, grid);
+    mix_run<1, 1>(in, out, n4 * 2, rounds, grid);
+    mix_run<2, 1>(in, out, n4 * 2, rounds, grid);
+    mix_run<4, 1>(in, out, n4, rounds, grid);
+    mix_run<1, 2>(in, out, n4, rounds, grid);
+  }
   return 0;
 }
 
 int main(int argc, char **argv) {
+  if (argc > 3 && std::string(argv[3]) == "mix") return mix_main(atoll(argv[1]), atoi(argv[2]));
+  if (argc > 3 && std::string(argv[3]) == "c16k") return c16k_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "spec") return spec_main(atoll(argv[1]), atoi(argv[2]));
   const int n = 4096;
   const long long batch = argc > 1 ? atoll(argv[1]) : 65536;
