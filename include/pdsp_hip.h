@@ -88,8 +88,10 @@ PDSP_API int pdsp_version(void);
 PDSP_API const char *pdsp_last_error(void);
 /* Number of visible HIP devices (0 when there is none); never fails. */
 PDSP_API int pdsp_device_count(void);
-/* Largest N for 4-byte / 8-byte scalars: 2^18 / 2^17.  Up to 16384 / 8192 (16384 for the f64
- * real-frame spectrum) one LDS-resident pass; above, a three-pass four-step transform. */
+/* Largest N for 4-byte / 8-byte scalars: 2^28 / 2^26.  Up to 16384 / 8192 (16384 for the f64
+ * real-frame spectrum) one LDS-resident pass; up to 16x that a three-pass four-step transform
+ * (columns fused into one kernel); above, the general five-pass four-step (both factors on the
+ * row kernels, tiled transposes between them). */
 PDSP_API int pdsp_max_size(int scalar_bytes);
 
 /* Kernel selection switch for A/B tests (process-wide; returns the previous value): 1 (default)
@@ -104,9 +106,9 @@ PDSP_API int pdsp_set_split16k(int enabled);
 PDSP_API int pdsp_set_staged_small(int enabled);
 
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).
- *   64 (default): f64 on the device for every size up to 2^17 -- the drop-in then meets the
+ *   64 (default): f64 on the device for every size up to 2^26 -- the drop-in then meets the
  *       reference's own test tolerances (1e-10 against NumPy, signals.test.ts:22-23), not just the
- *       f32 contract; N = 2^18 computes in f32.
+ *       f32 contract; N = 2^27, 2^28 compute in f32.
  *   32: always f32 (the north-star's stated contract, max|err|/max|X| <= 1e-5).
  * PDSP_HOST_PRECISION=32 in the environment presets it. */
 PDSP_API int pdsp_set_host_precision(int bits);
@@ -225,7 +227,7 @@ PDSP_API int pdsp_spectrum_peaks_f32(const pdsp_plan *plan, long long batch,
                                      pdsp_stream stream);
 
 /* ---- the same device-pointer family in f64 ------------------------------ */
-/* Identical contracts with double rows, N <= 2^17 (PDSP_ERR_UNSUPPORTED_SIZE beyond).
+/* Identical contracts with double rows, N <= 2^26 (PDSP_ERR_UNSUPPORTED_SIZE beyond).
  * ~1e-15 relative to max vs the f64 reference. */
 PDSP_API int pdsp_fft_forward_real_f64(const pdsp_plan *plan, long long batch,
                                        const double *re_in, double *re_out, double *im_out,

@@ -87,6 +87,7 @@ struct Tables {
   int log2n1 = 0;
   T2 *twa = nullptr;
   T2 *twb = nullptr;
+  T2 *tw1 = nullptr;  // general four-step path (log2n1 > kMaxLog2N1): radix table of the N1-point rows
   void release() {
     if (tw12) (void)hipFree(tw12);
     tw12 = nullptr;
@@ -95,7 +96,8 @@ struct Tables {
 
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
-    twa = twb = nullptr;
+    if (tw1) (void)hipFree(tw1);
+    twa = twb = tw1 = nullptr;
     if (tw) (void)hipFree(tw);
     if (tw_half) (void)hipFree(tw_half);
     if (twr) (void)hipFree(twr);
@@ -310,6 +312,49 @@ int fourstep_c(const pdsp_plan *plan, long long batch, const T *s_re, const T *s
   return PDSP_OK;
 }
 
+// General four-step path (log2n1 > kMaxLog2N1), steps 1-4 of bigfft_transpose_kernel's header:
+// transposes `in` into (a_re, a_im) = [n2][n1], N1-point rows in place, twiddled transpose into
+// (b_re, b_im) = [k1][n2], N2-point rows in place.  Step 5 is bigfft_out.
+template <typename T>
+int bigfft_rows(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, const T *win,
+                long long in_stride, long long used, T *a_re, T *a_im, T *b_re, T *b_im, hipStream_t s) {
+  const Tables<T> &t = tables<T>(plan);
+  const int n1 = 1 << t.log2n1, n2 = 1 << t.log2n2;
+  const long long tiles = batch * (plan->n / 1024);
+  if (tiles >= (1LL << 31) || (batch << t.log2n2) >= (1LL << 31))
+    return fail(PDSP_ERR_BAD_ARG, "batch %lld is too large for FFT size %lld", batch, plan->n);
+  hipLaunchKernelGGL((pdsp::bigfft_transpose_kernel<T, false, false>), dim3((unsigned)tiles), dim3(256), 0, s, re_in,
+                     im_in, win, used, in_stride, t.twa, t.twb, a_re, a_im, n1, n2, T(1), 0, 0, T(0), T(0));
+  PDSP_HIP_TRY(hipGetLastError());
+  {
+    pdsp::LoadComplex<T> ld{a_re, a_im, n1};
+    pdsp::StoreComplex<T> st{a_re, a_im, n1, T(1)};
+    if (t.log2n1 == t.log2n2) PDSP_HIP_TRY(launch_rows<T>(t, t.log2n1, ld, st, batch << t.log2n2, s, true));
+    else PDSP_HIP_TRY(launch_fft<T>(t.log2n1, ld, st, t.tw1, batch << t.log2n2, s));
+  }
+  hipLaunchKernelGGL((pdsp::bigfft_transpose_kernel<T, true, false>), dim3((unsigned)tiles), dim3(256), 0, s, a_re, a_im,
+                     (const T *)nullptr, plan->n, plan->n, t.twa, t.twb, b_re, b_im, n2, n1, T(1), 0, 0, T(0), T(0));
+  PDSP_HIP_TRY(hipGetLastError());
+  pdsp::LoadComplex<T> ld{b_re, b_im, n2};
+  pdsp::StoreComplex<T> st{b_re, b_im, n2, T(1)};
+  PDSP_HIP_TRY(launch_rows<T>(t, t.log2n2, ld, st, batch << t.log2n1, s, true));
+  return PDSP_OK;
+}
+
+// Step 5: [k1][k2] -> natural order.  AMP = false: complex planes (o1, o2) times `scale`;
+// AMP = true: amplitude rows o1 (and phase rows o2 unless null) of `bins` values.
+template <typename T, bool AMP>
+int bigfft_out(const pdsp_plan *plan, long long batch, const T *b_re, const T *b_im, T *o1, T *o2, T scale, int bins,
+               int nyq, T s_edge, T s_mid, hipStream_t s) {
+  const Tables<T> &t = tables<T>(plan);
+  const long long tiles = batch * (plan->n / 1024);
+  hipLaunchKernelGGL((pdsp::bigfft_transpose_kernel<T, false, AMP>), dim3((unsigned)tiles), dim3(256), 0, s, b_re, b_im,
+                     (const T *)nullptr, plan->n, plan->n, t.twa, t.twb, o1, o2, 1 << t.log2n1, 1 << t.log2n2, scale,
+                     bins, nyq, s_edge, s_mid);
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
 template <typename T>
 int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out, T scale,
                 hipStream_t s) {
@@ -318,10 +363,21 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   if (!re_in || !re_out || !im_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
   const Tables<T> &t = tables<T>(plan);
   if (!t.tw)
-    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit single-pass limit %d", plan->n,
-                (int)(8 * sizeof(T)), 1 << max_log2n<T>());
+    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit limit %d", plan->n, (int)(8 * sizeof(T)),
+                pdsp_max_size((int)sizeof(T)));
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
+  if (t.log2n1 > pdsp::kMaxLog2N1) {  // general four-step: the output planes double as the first scratch pair
+    const size_t plane = (size_t)batch * (size_t)plan->n;
+    const bool aliased = re_out == re_in || re_out == im_in || im_out == re_in || im_out == im_in;
+    T *scratch = nullptr;
+    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, (aliased ? 4 : 2) * plane * sizeof(T), s));
+    T *a_re = aliased ? scratch + 2 * plane : re_out, *a_im = aliased ? scratch + 3 * plane : im_out;
+    int rc = bigfft_rows<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, a_re, a_im, scratch, scratch + plane, s);
+    if (!rc) rc = bigfft_out<T, false>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
+    (void)hipFreeAsync(scratch, s);
+    return rc;
+  }
   if (t.log2n1 > 0) {  // beyond the single-pass limit: four-step through stream-ordered scratch planes
     T *scratch = nullptr;
     const size_t plane = (size_t)batch * (size_t)plan->n;
@@ -517,6 +573,11 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
       if (e == hipSuccess) e = hipMemcpy(t.twa, a.data(), a.size() * sizeof(T2), hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMalloc((void **)&t.twb, b.size() * sizeof(T2));
       if (e == hipSuccess) e = hipMemcpy(t.twb, b.data(), b.size() * sizeof(T2), hipMemcpyHostToDevice);
+      if (e == hipSuccess && t.log2n1 > pdsp::kMaxLog2N1) {
+        const std::vector<T2> t1 = build_twiddles<T2>(t.log2n1);
+        e = hipMalloc((void **)&t.tw1, t1.size() * sizeof(T2));
+        if (e == hipSuccess) e = hipMemcpy(t.tw1, t1.data(), t1.size() * sizeof(T2), hipMemcpyHostToDevice);
+      }
     }
   }
   if (e == hipSuccess && half) {
@@ -582,8 +643,8 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
   if ((phase_out || peak_idx_out) && !amp_out) return fail(PDSP_ERR_BAD_ARG, "phase/peak index output needs amp_out");
   const Tables<T> &t = tables<T>(plan);
   if (!t.tw && !t.tw_half)
-    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit single-pass limit", plan->n,
-                (int)(8 * sizeof(T)));
+    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit limit %d", plan->n, (int)(8 * sizeof(T)),
+                pdsp_max_size((int)sizeof(T)));
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
   static_assert(sizeof(pdsp_peak32) == sizeof(pdsp::PeakRec), "peak record layout");
@@ -599,17 +660,24 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     return PDSP_OK;
   }
   const T s_edge = T(1) / (T)n, s_mid = (sides == PDSP_SIDES_ONE ? T(2) : T(1)) / (T)n;
-  if (t.log2n1 > 0) {  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in pass C
+  if (t.log2n1 > 0) {  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in the last pass
+    const bool big = t.log2n1 > pdsp::kMaxLog2N1;  // general path: two scratch pairs
     T *scratch = nullptr, *amp = amp_out, *ph = phase_out;
-    const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins;
+    const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins, planes = big ? 4 : 2;
     const size_t extra = (peaks_out && !amp ? rows : 0) + (peaks_out && !ph ? rows : 0);
-    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, (2 * plane + extra) * sizeof(T), stream));
-    if (peaks_out && !amp) amp = scratch + 2 * plane;
-    if (peaks_out && !ph) ph = scratch + 2 * plane + (amp_out ? 0 : rows);
-    int rc = fourstep_ab<T>(plan, batch, frames, nullptr, window, frame_stride, used, scratch, scratch + plane, stream);
-    if (!rc)
-      rc = fourstep_c<T, 1>(plan, batch, scratch, scratch + plane, amp, ph, T(1), bins,
-                            (sides == PDSP_SIDES_ONE) ? (int)(n / 2) : -1, s_edge, s_mid, stream);
+    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, (planes * plane + extra) * sizeof(T), stream));
+    if (peaks_out && !amp) amp = scratch + planes * plane;
+    if (peaks_out && !ph) ph = scratch + planes * plane + (amp_out ? 0 : rows);
+    const int nyq = (sides == PDSP_SIDES_ONE) ? (int)(n / 2) : -1;
+    int rc;
+    if (big) {
+      rc = bigfft_rows<T>(plan, batch, frames, nullptr, window, frame_stride, used, scratch + 2 * plane,
+                          scratch + 3 * plane, scratch, scratch + plane, stream);
+      if (!rc) rc = bigfft_out<T, true>(plan, batch, scratch, scratch + plane, amp, ph, T(1), bins, nyq, s_edge, s_mid, stream);
+    } else {
+      rc = fourstep_ab<T>(plan, batch, frames, nullptr, window, frame_stride, used, scratch, scratch + plane, stream);
+      if (!rc) rc = fourstep_c<T, 1>(plan, batch, scratch, scratch + plane, amp, ph, T(1), bins, nyq, s_edge, s_mid, stream);
+    }
     if (!rc && peaks_out) {
       hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph, bins,
                          freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
@@ -825,9 +893,9 @@ int pdsp_device_count(void) {
   return count;
 }
 
-int pdsp_max_size(int scalar_bytes) {  // incl. the four-step path
-  if (scalar_bytes == 4) return 1 << (pdsp::kMaxLog2N_f32 + pdsp::kMaxLog2N1);
-  if (scalar_bytes == 8) return 1 << (pdsp::kMaxLog2N_f64 + pdsp::kMaxLog2N1);
+int pdsp_max_size(int scalar_bytes) {  // incl. the four-step paths
+  if (scalar_bytes == 4) return 1 << pdsp::kMaxLog2Big_f32;
+  if (scalar_bytes == 8) return 1 << pdsp::kMaxLog2Big_f64;
   return 0;
 }
 
@@ -927,9 +995,9 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
   *plan_out = nullptr;
   if (!pdsp_is_pow2(size)) return fail(PDSP_ERR_SIZE_NOT_POW2, "FFT size must be power of two, got %lld", size);
   const int log2n = ilog2ll(size);
-  if (log2n > pdsp::kMaxLog2N_f32 + pdsp::kMaxLog2N1)
+  if (log2n > pdsp::kMaxLog2Big_f32)
     return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the supported maximum %d", size,
-                1 << (pdsp::kMaxLog2N_f32 + pdsp::kMaxLog2N1));
+                1 << pdsp::kMaxLog2Big_f32);
   if (int rc = require_device()) return rc;
   int count = 0;
   PDSP_HIP_TRY(hipGetDeviceCount(&count));
@@ -942,13 +1010,13 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
   p->n = size;
   p->log2n = log2n;
   p->device = device;
-  // f32: single-pass up to 2^14, four-step (N1 <= 16 columns x 2^14-point rows) up to 2^18; the
-  // packed-real spectrum tables exist for the single-pass sizes
+  // f32: single-pass up to 2^14, four-step with fused columns (N1 <= 16) up to 2^18, general
+  // four-step (N1 x 2^14) up to 2^28; the packed-real spectrum tables exist for the single-pass sizes
   hipError_t e = upload_tables<float>(p->t32, log2n, size, true, log2n >= 6 && log2n <= pdsp::kMaxLog2N_f32);
-  // f64: the complex transform single-pass up to 2^13 and four-step up to 2^17; the packed-real
+  // f64: the complex transform single-pass up to 2^13 and four-step up to 2^26; the packed-real
   // spectrum (an N/2-point transform) up to N = 2^14
   if (e == hipSuccess)
-    e = upload_tables<double>(p->t64, log2n, size, log2n <= pdsp::kMaxLog2N_f64 + pdsp::kMaxLog2N1,
+    e = upload_tables<double>(p->t64, log2n, size, log2n <= pdsp::kMaxLog2Big_f64,
                               log2n >= 6 && log2n - 1 <= pdsp::kMaxLog2N_f64);
   if (e != hipSuccess) {
     p->t32.release();

@@ -1338,6 +1338,69 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
   }
 }
 
+// ---- general four-step path: N = N1 * N2 with 32 <= N1 <= N2 = the largest single-pass size ---
+// Input index n = n1*N2 + n2, output index k = k1 + N1*k2; both factors run on the row kernels,
+// so the data is transposed between them (Bailey's four-step):
+//   1  [n1][n2] -> [n2][n1]                       (this kernel; window / zero padding of real frames here)
+//   2  N1-point rows, in place                     (fft_stockham_kernel)
+//   3  [n2][k1] -> [k1][n2], times W_N^{n2*k1}     (this kernel, TW)
+//   4  N2-point rows, in place
+//   5  [k1][k2] -> [k2][k1] = natural order        (this kernel; 1/N of the inverse, or AMP: the
+//      amplitude / phase rows of spectrum())
+// Five passes over HBM -- a completeness path for long one-shot transforms, not a bench configuration.
+// One 256-thread workgroup moves one 32x32 tile of both planes through LDS, so the loads are
+// unit-stride along the input rows and the stores along the output rows.
+//   in: [batch][R][C] planar, element n = r*C + c; reads as zero for n >= used (real frames shorter
+//   than N); in_im may be null (real input); win (N values) may be null.
+template <typename T, bool TW, bool AMP>
+__global__ void __launch_bounds__(256)
+bigfft_transpose_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, const T *__restrict__ win,
+                        const long long used, const long long in_stride,
+                        const typename vec2<T>::type *__restrict__ twa, const typename vec2<T>::type *__restrict__ twb,
+                        T *__restrict__ o1, T *__restrict__ o2, const int R, const int C, const T scale, const int bins,
+                        const int nyq, const T s_edge, const T s_mid) {
+  __shared__ T tre[32][33], tim[32][33];
+  const int tiles_c = C / 32, tiles_r = R / 32;
+  const long long blk = (long long)blockIdx.x;
+  const long long b = blk / ((long long)tiles_r * tiles_c);
+  const int t = (int)(blk % ((long long)tiles_r * tiles_c));
+  const int tr = t / tiles_c, tc = t % tiles_c;
+  const int tx = (int)threadIdx.x & 31, ty = (int)threadIdx.x >> 5;
+  const T *const bre = in_re + (size_t)b * (size_t)in_stride;
+  const T *const bim = in_im ? in_im + (size_t)b * (size_t)in_stride : nullptr;
+  static_for<4>([&](auto ic) {
+    const int r = tr * 32 + ty + 8 * ic, c = tc * 32 + tx;
+    const long long n = (long long)r * C + c;
+    const long long nc = n < used ? n : used - 1;  // unconditional clamped loads + select
+    cx<T> v{bre[nc], bim ? bim[nc] : T(0)};
+    if (win) v = v * win[n];
+    if (n >= used) v = cx<T>{T(0), T(0)};
+    if constexpr (TW) {
+      const unsigned m = (unsigned)r * (unsigned)c;  // < N <= 2^28
+      v = cmul(v, cmul(reinterpret_cast<const cx<T> *>(twa)[m >> 9], reinterpret_cast<const cx<T> *>(twb)[m & 511]));
+    }
+    tre[ty + 8 * ic][tx] = v.x;
+    tim[ty + 8 * ic][tx] = v.y;
+  });
+  __syncthreads();
+  static_for<4>([&](auto ic) {
+    const int orow = tc * 32 + ty + 8 * ic, ocol = tr * 32 + tx;  // output matrix is [C][R]
+    const cx<T> v{tre[tx][ty + 8 * ic], tim[tx][ty + 8 * ic]};
+    const long long k = (long long)orow * R + ocol;
+    if constexpr (AMP) {
+      if (k < bins) {
+        const size_t o = (size_t)b * (size_t)bins + (size_t)k;
+        o1[o] = mag(v) * ((k == 0 || k == nyq) ? s_edge : s_mid);
+        if (o2) o2[o] = T(atan2(v.y, v.x));
+      }
+    } else {
+      const size_t o = (size_t)b * (size_t)R * (size_t)C + (size_t)k;
+      o1[o] = v.x * scale;
+      o2[o] = v.y * scale;
+    }
+  });
+}
+
 // SpectrumPeak per frame from stored amplitude (and phase) rows: the fallback of the fused
 // PEAK path for sizes / alignments the packed kernel does not take.  One workgroup per row.
 template <typename T>

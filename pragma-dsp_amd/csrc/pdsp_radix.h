@@ -15,6 +15,9 @@ constexpr int kMaxPasses = 5;
 constexpr int kMaxLog2N_f32 = 14;  // (N + N/16) * 8 B of LDS <= 160 KiB
 constexpr int kMaxLog2N_f64 = 13;  // (N + N/16) * 16 B
 constexpr int kMaxLog2N1 = 4;      // four-step path: N = N1 * N2, N1 <= 16 columns per thread
+// general four-step path (N1 > 16: both factors run on the single-pass row kernels)
+constexpr int kMaxLog2Big_f32 = 2 * kMaxLog2N_f32;  // 2^28
+constexpr int kMaxLog2Big_f64 = 2 * kMaxLog2N_f64;  // 2^26
 
 struct RadixPlan {
   int log2n;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pdsp):
     # and the ctypes binding covers all of them
     assert set(syms) == set(pdsp.lib._pdsp_symbols)
     assert pdsp.lib.pdsp_version() >= 100
-    assert pdsp.lib.pdsp_max_size(4) == 262144 and pdsp.lib.pdsp_max_size(8) == 131072
+    assert pdsp.lib.pdsp_max_size(4) == 1 << 28 and pdsp.lib.pdsp_max_size(8) == 1 << 26
 
 
 def test_product_does_not_touch_the_oracle():
@@ -109,7 +109,7 @@ def test_c_abi_status_codes_without_device(pdsp):
     h = C.c_void_p()
     assert lib.pdsp_plan_create(12, -1, C.byref(h)) == _capi.ERR_SIZE_NOT_POW2
     assert lib.pdsp_last_error() == b"FFT size must be power of two, got 12"
-    assert lib.pdsp_plan_create(1 << 20, -1, C.byref(h)) == _capi.ERR_UNSUPPORTED_SIZE
+    assert lib.pdsp_plan_create(1 << 29, -1, C.byref(h)) == _capi.ERR_UNSUPPORTED_SIZE
     out = np.empty(4)
     assert lib.pdsp_window_make(1, 0, out.ctypes.data_as(C.POINTER(C.c_double))) == _capi.ERR_WINDOW_SIZE
     assert lib.pdsp_last_error() == b"Window size must be positive, got 0"

@@ -92,7 +92,7 @@ def test_f32_mode_is_the_north_star_contract(pdsp, reallife):
         assert 1e-9 < err <= 1e-5      # f32 arithmetic, inside the stated tolerance
     finally:
         pdsp.lib.pdsp_set_host_precision(prev)
-    big = pdsp.FFT(1 << 18).forward(np.ones(1 << 18))   # beyond the f64 limit (2^17): computed in f32
+    big = pdsp.FFT(1 << 18).forward(np.ones(1 << 18))   # four-step path
     assert abs(big.real[0] - (1 << 18)) < 1 and np.abs(big.real[1:]).max() == 0
 
 
@@ -121,11 +121,11 @@ def test_f64_device_family(oracle_mod, log2n):
 def test_f64_limits(pdsp):
     import torch
     from pragma_dsp_amd.batch import BatchedFft
-    with pytest.raises(pdsp.PdspError, match="single-pass limit"):
-        BatchedFft(1 << 18, "cuda:0", dtype=torch.float64).forward(torch.zeros((1, 1 << 18), device="cuda", dtype=torch.float64))
+    with pytest.raises(pdsp.PdspError, match="exceeds the 64-bit limit 67108864"):  # f64 stops at 2^26, f32 at 2^28
+        BatchedFft(1 << 27, "cuda:0", dtype=torch.float64).forward(torch.zeros((1, 1 << 27), device="cuda", dtype=torch.float64))
     plan = BatchedFft(16384, "cuda:0", dtype=torch.float64)
     x = torch.randn((2, 16384), device="cuda", dtype=torch.float64)
     amp, _, _ = plan.spectrum(x, "rect", "one")  # single-pass packed-real path (an 8192-point transform)
     energy = (amp[:, 0] ** 2 + amp[:, -1] ** 2 + 0.5 * (amp[:, 1:-1] ** 2).sum(dim=1)) * 16384
     assert float(((energy - (x ** 2).sum(dim=1)).abs() / (x ** 2).sum(dim=1)).max()) < 1e-13
-    assert pdsp.lib.pdsp_max_size(8) == 131072 and pdsp.lib.pdsp_max_size(4) == 262144
+    assert pdsp.lib.pdsp_max_size(8) == 1 << 26 and pdsp.lib.pdsp_max_size(4) == 1 << 28

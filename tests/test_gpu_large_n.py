@@ -1,5 +1,6 @@
-"""N beyond the single-pass LDS limit (the reference takes any power of two): the four-step path,
-f32 up to 2^18 and f64 up to 2^17, vs the f64 oracle."""
+"""N beyond the single-pass LDS limit (the reference takes any power of two): the four-step paths
+-- fused columns for N1 <= 16 (f32 up to 2^18, f64 up to 2^17), the general transposed form above
+(f32 up to 2^28, f64 up to 2^26) -- vs the f64 oracle."""
 import numpy as np
 import pytest
 
@@ -8,14 +9,15 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("log2n", [15, 16, 17, 18])
+@pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20, 22])
 def test_large_complex_real_inverse_f32(oracle_mod, log2n):
     import torch
     from pragma_dsp_amd.batch import BatchedFft
     n = 1 << log2n
     rng = np.random.default_rng(log2n)
-    re = rng.standard_normal((3, n)).astype(np.float32)
-    im = rng.standard_normal((3, n)).astype(np.float32)
+    batch = 3 if log2n <= 20 else 1
+    re = rng.standard_normal((batch, n)).astype(np.float32)
+    im = rng.standard_normal((batch, n)).astype(np.float32)
     plan = BatchedFft(n, "cuda:0")
     dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
     ore, oim = plan.forward(dre, dim)
@@ -28,7 +30,7 @@ def test_large_complex_real_inverse_f32(oracle_mod, log2n):
     assert rel_err(rre.cpu().numpy().astype(np.float64) + 1j * rim.cpu().numpy(), wre + 1j * wim) <= 1e-5
 
 
-@pytest.mark.parametrize("log2n", [14, 15, 17])
+@pytest.mark.parametrize("log2n", [14, 15, 17, 18, 19, 21])
 def test_large_f64(oracle_mod, log2n):
     import torch
     from pragma_dsp_amd.batch import BatchedFft
@@ -68,3 +70,38 @@ def test_large_spectrum_device_and_dropin(pdsp, oracle_mod):
     big = pdsp.Radix2Fft(1 << 18)      # f32 beyond 2^17
     out = big.forward(np.cos(2 * np.pi * 5 * np.arange(1 << 18) / (1 << 18)))
     assert abs(out.real[5] - (1 << 17)) < 1 and abs(out.real[(1 << 18) - 5] - (1 << 17)) < 1
+
+
+def test_general_four_step_spectrum_aliasing_and_dropin(pdsp, oracle_mod):
+    """N = 2^20 (N1 = 64 rows x N2 = 16384): windowed spectrum rows, fused peaks, an in-place
+    transform (output planes aliasing the input), and the drop-in on a 600,000-sample signal."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 1 << 20
+    rng = np.random.default_rng(20)
+    t = np.arange(n)
+    x = (rng.standard_normal((2, n)) * 0.1 + np.sin(2 * np.pi * 54321 * t / n)).astype(np.float32)
+    plan = BatchedFft(n, "cuda:0")
+    win = oracle_mod.create_window("blackman", n).astype(np.float32)
+    for sides in ("one", "two"):
+        amp, ph, pk = plan.spectrum(torch.from_numpy(x).cuda(), "blackman", sides, want_phase=True, want_peak=True)
+        wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, two_sided=(sides == "two"),
+                                                           want_phase=True, want_peak=True)
+        assert amp.shape == wamp.shape and rel_err(amp.cpu().numpy(), wamp) <= 1e-5
+        assert all(int(v) in (54321, n - 54321 if sides == "two" else 54321) for v in pk.cpu())
+        mask = wamp > 1e-2 * wamp.max(axis=-1, keepdims=True)
+        d = np.abs((ph.cpu().numpy() - wph + np.pi) % (2 * np.pi) - np.pi)
+        assert d[mask].max() <= 2e-3
+    idx, freq, a, p, _, _ = plan.spectrum_peaks(torch.from_numpy(x[:, :600000].copy()).cuda(), "hann", "one", 48000.0)
+    assert [int(v) for v in idx.cpu()] == [54321, 54321]
+    # in place: out planes are the input planes
+    re = torch.from_numpy(x[:1].copy()).cuda()
+    im = torch.zeros_like(re)
+    want_re, want_im = oracle_mod.Plan(n).forward(x[:1])
+    plan.forward(re, im, out=(re, im))
+    assert rel_err(re.cpu().numpy().astype(np.float64) + 1j * im.cpu().numpy(), want_re + 1j * want_im) <= 1e-5
+    sig = np.sin(2 * np.pi * 440.0 * np.arange(600000) / 48000.0)
+    g = pdsp.spectrum(sig, {"sampleRate": 48000, "window": "hann"})   # nextPowerOfTwo(600000) = 2^20, f64
+    w = oracle_mod.spectrum(sig, sample_rate=48000, window="hann")
+    assert len(g.amplitude) == (1 << 19) + 1 and g.peak.index == w["peak"]["index"]
+    assert np.abs(g.amplitude - w["amplitude"]).max() <= 1e-12

@@ -127,8 +127,8 @@ def test_error_paths_on_device(pdsp):
         BatchedFft(48, "cuda:0")
     with pytest.raises(pdsp.PdspError, match="FFT input length 5 != size 8"):
         pdsp.Radix2Fft(8).forward([1, 2, 3, 4, 5])
-    with pytest.raises(pdsp.PdspError, match="exceeds the supported maximum 262144"):
-        pdsp.Radix2Fft(1 << 19)
+    with pytest.raises(pdsp.PdspError, match="exceeds the supported maximum 268435456"):
+        pdsp.Radix2Fft(1 << 29)
     out = plan.forward(torch.zeros((0, 64), device="cuda"))  # empty batch: no launch
     assert out[0].shape == (0, 64)
     assert pdsp.lib.pdsp_plan_cache_clear() == 0
