@@ -231,9 +231,11 @@ def main() -> int:
         ore, oim = torch.empty_like(re), torch.empty_like(im)
         launches_per_step = 1
         bytes_per_launch = 16 * per_gpu * n  # 8 B read + 8 B written per sample
-        kernel_name, kernel_label = "LoadComplex", "fft_stockham_kernel<float, 12, LoadComplex, StoreComplex>"
+        kernel_name, kernel_label = "fft_stockham_kernel<float, 12, pdsp::LoadComplex", \
+            "fft_stockham_kernel<float, 12, LoadComplex, StoreComplex>"
         if args.workload == "fft16k":
-            kernel_name, kernel_label = "fft_split4", "fft_split4_kernel<float, 12, LoadComplex, StoreComplex>"
+            kernel_name, kernel_label = "fft_split4_kernel<float, 12, pdsp::LoadComplex", \
+                "fft_split4_kernel<float, 12, LoadComplex, StoreComplex>"
 
         def step():
             plan.forward(re, im, out=(ore, oim))
@@ -243,7 +245,8 @@ def main() -> int:
         ore, oim = torch.empty_like(re), torch.empty_like(re)
         launches_per_step = 1
         bytes_per_launch = 12 * per_gpu * n
-        kernel_name, kernel_label = "LoadReal", "fft_stockham_kernel<float, 12, LoadReal, StoreComplex>"
+        kernel_name, kernel_label = "fft_stockham_kernel<float, 12, pdsp::LoadReal", \
+            "fft_stockham_kernel<float, 12, LoadReal, StoreComplex>"
 
         def step():
             plan.forward(re, None, out=(ore, oim))
