@@ -453,6 +453,29 @@ int ensure_stage(pdsp_plan *plan, size_t bytes) {
   return PDSP_OK;
 }
 
+// One-frame calls are latency-bound (two small copies + one kernel + one sync).  Below this size
+// the kernel reads the frame from, and writes the result to, the pinned staging buffer itself
+// (hipHostMalloc memory is mapped into the device's address space): no copy commands at all.
+// PDSP_ZERO_COPY=0 in the environment restores the staged copies (A/B, tests).
+constexpr size_t kZeroCopyBytes = 256 * 1024;
+int g_zero_copy = -1;
+bool zero_copy(size_t bytes) {
+  if (g_zero_copy < 0) {
+    const char *e = getenv("PDSP_ZERO_COPY");
+    g_zero_copy = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return g_zero_copy == 1 && bytes <= kZeroCopyBytes;
+}
+template <typename T>
+T *stage_device_view(pdsp_plan *plan) {  // device-side address of the pinned staging buffer
+  void *dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, plan->h_stage, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return (T *)dp;
+}
+
 // Scratch (plan-less) staging for the element-wise host entry points.
 template <typename T>
 struct Scratch {
@@ -785,14 +808,19 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
   if (im_in)
     for (size_t i = 0; i < cnt; ++i) h_im[i] = (T)im_in[i];
   hipStream_t s = plan->stream;
-  PDSP_HIP_TRY(hipMemcpyAsync(d_re, h_re, (im_in ? 2 : 1) * cnt * sizeof(T), hipMemcpyHostToDevice, s));
+  T *const z = zero_copy(4 * cnt * sizeof(T)) ? stage_device_view<T>(plan) : nullptr;
+  if (z) {  // the kernels work on the pinned buffer itself
+    d_re = z, d_im = z + cnt, d_ore = z + 2 * cnt, d_oim = z + 3 * cnt;
+  } else {
+    PDSP_HIP_TRY(hipMemcpyAsync(d_re, h_re, (im_in ? 2 : 1) * cnt * sizeof(T), hipMemcpyHostToDevice, s));
+  }
   int rc;
   // inverse: conj(FFT(conj(z))) == swap(FFT(swap(z))) -- the conjugated-twiddle sweep of fft.ts:122
   // is the forward kernel with the planes exchanged on the way in and out; 1/N rides on the store
   if (inverse) rc = run_complex<T>(plan, batch, d_im, d_re, d_oim, d_ore, T(1) / (T)plan->n, s);
   else rc = run_complex<T>(plan, batch, d_re, im_in ? d_im : nullptr, d_ore, d_oim, T(1), s);
   if (rc) return rc;
-  PDSP_HIP_TRY(hipMemcpyAsync(h_ore, d_ore, 2 * cnt * sizeof(T), hipMemcpyDeviceToHost, s));
+  if (!z) PDSP_HIP_TRY(hipMemcpyAsync(h_ore, d_ore, 2 * cnt * sizeof(T), hipMemcpyDeviceToHost, s));
   PDSP_HIP_TRY(hipStreamSynchronize(s));
   for (size_t i = 0; i < cnt; ++i) re_out[i] = (double)h_ore[i];
   for (size_t i = 0; i < cnt; ++i) im_out[i] = (double)h_oim[i];
@@ -866,10 +894,12 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int w
     if (int rc = plan_window<T>(plan, window, &d_window)) return rc;
   }
   hipStream_t s = plan->stream;
-  PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(T), hipMemcpyHostToDevice, s));
+  T *const z = zero_copy((size_t)(2 * n + 2 * bins) * sizeof(T)) ? stage_device_view<T>(plan) : nullptr;
+  if (z) d = z;  // the kernel works on the pinned buffer itself
+  else PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(T), hipMemcpyHostToDevice, s));
   if (int rc = spectrum_impl<T>(plan, 1, d, n, n, d_window, sides, d + 2 * n, d + 2 * n + bins, nullptr, nullptr, 1.0, s))
     return rc;
-  PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * n, d + 2 * n, (size_t)(2 * bins) * sizeof(T), hipMemcpyDeviceToHost, s));
+  if (!z) PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * n, d + 2 * n, (size_t)(2 * bins) * sizeof(T), hipMemcpyDeviceToHost, s));
   PDSP_HIP_TRY(hipStreamSynchronize(s));
   for (long long i = 0; i < bins; ++i) amp_out[i] = (double)h[2 * n + i];
   for (long long i = 0; i < bins; ++i) phase_out[i] = (double)h[2 * n + bins + i];
