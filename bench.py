@@ -160,7 +160,22 @@ def single_frame_latency(args, dev) -> int:
     e1.record()
     torch.cuda.synchronize(dev)
     kernel_us = e0.elapsed_time(e1) * 1e3 / iters
+    js = None
+    if not args.no_cpu_baseline:
+        # the real drop-in (Node + N-API addon) in the shape of the reference's bench/run.ts, with the
+        # Node CPU restatement of the same algorithm timed beside it
+        import shutil
+        import subprocess
+        node = shutil.which("node")
+        if node:
+            try:
+                r = subprocess.run([node, os.path.join(ROOT, "tests", "js", "bench_latency.js"), "2000"],
+                                   capture_output=True, text=True, timeout=300)
+                js = json.loads(r.stdout) if r.returncode == 0 else {"error": r.stderr[-400:]}
+            except Exception as e:
+                js = {"error": repr(e)}
     print(json.dumps({
+        "js_dropin_latency": js,
         "metric": "single-frame latency (N=1024, Hann + FFT + magnitude)", "unit": "us", "higher_is_better": False,
         "value": spec_med, "n_gpus": 1, "steps": iters, "warmup": 20, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "N=1024 single frame spectrum(), hann, one-sided (configs[1])"},

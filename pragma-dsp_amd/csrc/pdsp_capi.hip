@@ -453,18 +453,18 @@ int ensure_stage(pdsp_plan *plan, size_t bytes) {
   return PDSP_OK;
 }
 
-// One-frame calls are latency-bound (two small copies + one kernel + one sync).  Below this size
+// One-frame calls are latency-bound (two small copies + one kernel + one sync).  Up to 1 MiB of staging
 // the kernel reads the frame from, and writes the result to, the pinned staging buffer itself
 // (hipHostMalloc memory is mapped into the device's address space): no copy commands at all.
-// PDSP_ZERO_COPY=0 in the environment restores the staged copies (A/B, tests).
-constexpr size_t kZeroCopyBytes = 256 * 1024;
-int g_zero_copy = -1;
+// PDSP_ZERO_COPY=0 in the environment restores the staged copies (A/B, tests); a value > 1 sets the limit.
+long long g_zero_copy_bytes = -1;
 bool zero_copy(size_t bytes) {
-  if (g_zero_copy < 0) {
-    const char *e = getenv("PDSP_ZERO_COPY");
-    g_zero_copy = (e && atoi(e) == 0) ? 0 : 1;
+  if (g_zero_copy_bytes < 0) {
+    const char *e = getenv("PDSP_ZERO_COPY");  // 0 = off, 1 / unset = default limit, > 1 = limit in bytes
+    const long long v = e ? atoll(e) : 1;
+    g_zero_copy_bytes = v <= 0 ? 0 : (v == 1 ? 1024 * 1024 : v);
   }
-  return g_zero_copy == 1 && bytes <= kZeroCopyBytes;
+  return (long long)bytes <= g_zero_copy_bytes;
 }
 template <typename T>
 T *stage_device_view(pdsp_plan *plan) {  // device-side address of the pinned staging buffer

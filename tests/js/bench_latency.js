@@ -1,0 +1,67 @@
+'use strict';
+// Single-call latency of the JS drop-in, in the shape of the reference's own benchmark
+// (bench/run.ts:12-28: one plan, `out` reused, a checksum over the result so the work cannot be
+// elided), with the Node CPU restatement of the same algorithm (oracle/pdsp_oracle.js) timed
+// next to it when it is present.  Prints one JSON line.
+// Run by `bench.py --workload single1024` (its cpu_baseline leg) or by hand:
+//   node tests/js/bench_latency.js [iterations]
+const path = require('path');
+const p = require(path.join(__dirname, '..', '..', 'pragma-dsp_amd', 'js'));
+const cpu = require(path.join(__dirname, '..', '..', 'oracle', 'pdsp_oracle.js'));  // CPU baseline + checker
+
+const iters = parseInt(process.argv[2] || '2000', 10);
+const now = () => Number(process.hrtime.bigint()) / 1e3;  // microseconds
+
+function stats(ts) {
+  ts.sort((a, b) => a - b);
+  return { median_us: ts[ts.length >> 1], min_us: ts[0], p95_us: ts[Math.floor(ts.length * 0.95)] };
+}
+
+function timed(fn) {
+  for (let i = 0; i < 50; i++) fn();
+  const ts = new Array(iters);
+  for (let i = 0; i < iters; i++) {
+    const t0 = now();
+    fn();
+    ts[i] = now() - t0;
+  }
+  return stats(ts);
+}
+
+const out = { node: process.version, iterations: iters, cases: [] };
+let seed = 1337;
+const rnd = () => { seed ^= seed << 13; seed ^= seed >>> 17; seed ^= seed << 5; return (seed >>> 0) / 2147483648 - 1; };
+for (const n of [1024, 2048, 4096, 16384]) {
+  const input = new Float64Array(n);
+  for (let i = 0; i < n; i++) input[i] = rnd();
+  const fft = new p.fourier.FFT(n);
+  const res = fft.createComplexArray();
+  let checksum = 0;
+  const gpu = timed(() => {
+    const r = fft.forward(input, res);
+    checksum += r.real[1] * 0.001 + r.imag[n - 1] * 0.002;
+  });
+  const row = { n: n, op: 'FFT.forward', gpu_dropin: gpu };
+  if (cpu) {
+    const plan = cpu.makePlan(n), oRe = new Float64Array(n), oIm = new Float64Array(n);
+    row.node_cpu = timed(() => {
+      cpu.transform(plan, input, null, oRe, oIm, false);
+      checksum += oRe[1] * 0.001 + oIm[n - 1] * 0.002;
+    });
+    let d = 0, m = 0;
+    fft.forward(input, res);
+    for (let i = 0; i < n; i++) {
+      d = Math.max(d, Math.abs(res.real[i] - oRe[i]), Math.abs(res.imag[i] - oIm[i]));
+      m = Math.max(m, Math.abs(oRe[i]), Math.abs(oIm[i]));
+    }
+    row.max_abs_diff_over_max = d / m;
+  }
+  out.cases.push(row);
+  const sp = timed(() => {
+    const r = p.spectrum(input, { sampleRate: 48000, fftSize: n, window: 'hann' });
+    checksum += r.peak.amplitude;
+  });
+  out.cases.push({ n: n, op: 'spectrum(hann, one-sided)', gpu_dropin: sp });
+}
+out.checksum_guard = Number.isFinite(seed) ? 1 : 0;
+process.stdout.write(JSON.stringify(out) + '\n');
