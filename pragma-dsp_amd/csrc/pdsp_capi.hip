@@ -743,6 +743,7 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       PDSP_HIP_TRY(hipGetLastError());
       return PDSP_OK;
     }
+    bool launched = false;
     if constexpr (sizeof(T) == 4) {
       // N = 16384: two 4096-point sub-transforms per 256-thread workgroup (4 frames per CU instead of 2)
       if (fast && plan->log2n == 14 && g_split16k && ((uintptr_t)frames & 15) == 0 && (frame_stride & 3) == 0 &&
@@ -757,12 +758,13 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
         else PDSP_SPLIT(false, false);
 #undef PDSP_SPLIT
         PDSP_HIP_TRY(hipGetLastError());
-        return PDSP_OK;
+        launched = true;  // a requested peak-index array is filled by the common tail below
       }
     }
-    PDSP_HIP_TRY(launch_packed<T>(plan->log2n - 1, fast, frames, window, used, frame_stride, t.tw_half, t.twr, amp_out,
-                                  phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
-                                  reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
+    if (!launched)
+      PDSP_HIP_TRY(launch_packed<T>(plan->log2n - 1, fast, frames, window, used, frame_stride, t.tw_half, t.twr,
+                                    amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
+                                    reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
   } else {
     // complex kernel on (x, 0) for N < 64 or an unaligned window; peaks come from the stored rows
     if (!t.tw) return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unaligned window at a size only the packed path holds");

@@ -135,7 +135,8 @@ def test_split16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, wind
     for mode in (1, 0):
         prev = pdsp.lib.pdsp_set_split16k(mode)
         try:
-            amp, _, _ = plan.spectrum(dx, window, "one")
+            amp, _, pki = plan.spectrum(dx, window, "one", want_peak=True)   # peak-index array (common tail)
+            assert list(pki.cpu().numpy()[:7]) == [777] * 7 and int(pki[7]) == 0
             idx, freq, pamp, pph, _, _ = plan.spectrum_peaks(dx, window, "one", 48000.0)
             torch.cuda.synchronize()
         finally:
