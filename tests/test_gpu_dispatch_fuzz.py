@@ -94,3 +94,83 @@ def test_spectrum_dispatch_fuzz(oracle_mod, seed):
             assert p[0] == 0, ctx
             for b in range(1, batch):   # same bin, or a bin whose amplitude ties within tolerance
                 assert abs(wamp[b, p[b]] - wamp[b, wpk[b]]) <= 2 * TOL * wamp[b].max(), ctx
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_host_dropin_spectrum_fuzz(pdsp, oracle_mod, seed):
+    """spectrum(samples, options) through the host drop-in (default f64 mode) with random lengths,
+    fftSize present or absent, windows, sides and sample rates: every field against the oracle."""
+    rng = np.random.default_rng(3000 + seed)
+    prev = pdsp.lib.pdsp_set_host_precision(64)
+    try:
+        for _ in range(25):
+            length = int(rng.choice([1, 2, 3, 5, 8, 100, 1000, 1024, 4097, int(rng.integers(1, 40000))]))
+            x = rng.standard_normal(length) + 0.5 * np.sin(2 * np.pi * 0.123 * np.arange(length))
+            opts = {"sampleRate": float(rng.choice([1.0, 8000.0, 44100.0, 48000.0]))}
+            if rng.integers(0, 2):
+                opts["fftSize"] = 1 << int(rng.integers(0, 16))
+            opts["window"] = str(rng.choice(["rect", "hann", "hamming", "blackman"]))
+            opts["sides"] = str(rng.choice(["one", "two"]))
+            g = pdsp.spectrum(x, opts)
+            w = oracle_mod.spectrum(x, sample_rate=opts["sampleRate"], fft_size=opts.get("fftSize"),
+                                    window=opts["window"], sides=opts["sides"])
+            ctx = (length, opts)
+            assert np.array_equal(g.frequencies, w["frequencies"]), ctx
+            scale = max(np.abs(w["amplitude"]).max(), 1e-300)
+            assert np.abs(g.amplitude - w["amplitude"]).max() <= 1e-12 * max(1.0, scale), ctx
+            n = len(w["frequencies"]) if opts["sides"] == "two" else 2 * (len(w["frequencies"]) - 1)
+            if n <= 2 and opts["window"] in ("hann", "blackman"):
+                continue  # an all-(near-)zero window: peak and phase are decided by rounding noise
+            # peak: same bin, or a bin whose amplitude ties to rounding (two-sided mirror, SURVEY H2)
+            assert abs(w["amplitude"][g.peak.index] - w["peak"]["amplitude"]) <= 1e-12 * max(1.0, scale), ctx
+            assert g.peak.frequency == g.frequencies[g.peak.index] and g.peak.amplitude == g.amplitude[g.peak.index], ctx
+            assert g.peak.phase == g.phase[g.peak.index], ctx
+            mask = w["amplitude"] > 1e-6 * scale
+            d = np.abs((g.phase - w["phase"] + np.pi) % (2 * np.pi) - np.pi)
+            assert d[mask].max(initial=0) <= 1e-8, ctx
+    finally:
+        pdsp.lib.pdsp_set_host_precision(prev)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fused_peaks_fuzz(oracle_mod, seed):
+    """pdsp_spectrum_peaks_f32 (findPeak fused into the kernel, or the row fallback) on random
+    sizes / lengths / alignments; frames carry one dominant tone so the expected bin is unambiguous."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    rng = np.random.default_rng(4000 + seed)
+    plans = {}
+    for _ in range(25):
+        log2n = int(rng.integers(3, 17))
+        n = 1 << log2n
+        batch = int(rng.integers(1, max(2, min(100, (1 << 20) // n))))
+        length = int(rng.choice([n, n, max(n // 2 + 1, n - int(rng.integers(0, n // 4 + 1)))]))
+        off = int(rng.choice([0, 0, 1, 4]))
+        window = str(rng.choice(["rect", "hann", "blackman"]))
+        sides = str(rng.choice(["one", "one", "two"]))
+        with_rows = bool(rng.integers(0, 2))
+        k = rng.integers(1, n // 2, size=batch)
+        t = np.arange(length)
+        x = (np.sin(2 * np.pi * k[:, None] * t[None, :] / n + 0.3) + 0.01 * rng.standard_normal((batch, length))).astype(np.float32)
+        plan = plans.setdefault(n, BatchedFft(n, "cuda:0"))
+        dx = _offset_view(torch, batch, length, off)
+        dx.copy_(torch.from_numpy(x))
+        idx, freq, pamp, pph, amp, ph = plan.spectrum_peaks(dx, window, sides, 48000.0, want_amp=with_rows,
+                                                            want_phase=with_rows)
+        frame = np.zeros((batch, n), dtype=np.float32)
+        frame[:, :length] = x
+        win = oracle_mod.create_window(window, n).astype(np.float32) if window != "rect" else None
+        wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(frame, window=win, two_sided=(sides == "two"),
+                                                           want_phase=True, want_peak=True)
+        ctx = (log2n, batch, length, off, window, sides, with_rows)
+        gi = idx.cpu().numpy()
+        for b in range(batch):
+            assert gi[b] in (wpk[b], (n - wpk[b]) if sides == "two" else wpk[b]) or \
+                abs(wamp[b, gi[b]] - wamp[b, wpk[b]]) <= 2 * TOL * wamp[b].max(), ctx
+        rows = np.arange(batch)
+        assert np.abs(pamp.cpu().numpy() - wamp[rows, gi]).max() <= TOL * wamp.max(), ctx
+        assert np.abs(freq.cpu().numpy() - gi * 48000.0 / n).max() <= 48000.0 * 1e-6, ctx
+        d = np.abs((pph.cpu().numpy() - wph[rows, gi] + np.pi) % (2 * np.pi) - np.pi)
+        assert d.max() <= 5e-3, ctx
+        if with_rows:
+            assert rel_err(amp.cpu().numpy(), wamp) <= TOL, ctx
