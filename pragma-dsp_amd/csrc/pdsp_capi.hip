@@ -45,6 +45,19 @@ int fail(int code, const char *fmt, ...) {
       return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #expr); \
   } while (0)
 
+// Stream-ordered scratch that is handed back on every exit path.
+struct StreamScratch {
+  void *p = nullptr;
+  hipStream_t s;
+  explicit StreamScratch(hipStream_t stream) : s(stream) {}
+  StreamScratch(const StreamScratch &) = delete;
+  StreamScratch &operator=(const StreamScratch &) = delete;
+  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes, s); }
+  ~StreamScratch() {
+    if (p) (void)hipFreeAsync(p, s);
+  }
+};
+
 struct DeviceGuard {
   int prev = -1;
   bool switched = false;
@@ -370,21 +383,21 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   if (t.log2n1 > pdsp::kMaxLog2N1) {  // general four-step: the output planes double as the first scratch pair
     const size_t plane = (size_t)batch * (size_t)plan->n;
     const bool aliased = re_out == re_in || re_out == im_in || im_out == re_in || im_out == im_in;
-    T *scratch = nullptr;
-    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, (aliased ? 4 : 2) * plane * sizeof(T), s));
+    StreamScratch mem(s);
+    PDSP_HIP_TRY(mem.alloc((aliased ? 4 : 2) * plane * sizeof(T)));
+    T *const scratch = (T *)mem.p;
     T *a_re = aliased ? scratch + 2 * plane : re_out, *a_im = aliased ? scratch + 3 * plane : im_out;
     int rc = bigfft_rows<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, a_re, a_im, scratch, scratch + plane, s);
     if (!rc) rc = bigfft_out<T, false>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
-    (void)hipFreeAsync(scratch, s);
     return rc;
   }
   if (t.log2n1 > 0) {  // beyond the single-pass limit: four-step through stream-ordered scratch planes
-    T *scratch = nullptr;
     const size_t plane = (size_t)batch * (size_t)plan->n;
-    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, 2 * plane * sizeof(T), s));
+    StreamScratch mem(s);
+    PDSP_HIP_TRY(mem.alloc(2 * plane * sizeof(T)));
+    T *const scratch = (T *)mem.p;
     int rc = fourstep_ab<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, scratch, scratch + plane, s);
     if (!rc) rc = fourstep_c<T, 0>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
-    (void)hipFreeAsync(scratch, s);
     return rc;
   }
   hipError_t e;
@@ -685,10 +698,12 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
   const T s_edge = T(1) / (T)n, s_mid = (sides == PDSP_SIDES_ONE ? T(2) : T(1)) / (T)n;
   if (t.log2n1 > 0) {  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in the last pass
     const bool big = t.log2n1 > pdsp::kMaxLog2N1;  // general path: two scratch pairs
-    T *scratch = nullptr, *amp = amp_out, *ph = phase_out;
+    T *amp = amp_out, *ph = phase_out;
     const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins, planes = big ? 4 : 2;
     const size_t extra = (peaks_out && !amp ? rows : 0) + (peaks_out && !ph ? rows : 0);
-    PDSP_HIP_TRY(hipMallocAsync((void **)&scratch, (planes * plane + extra) * sizeof(T), stream));
+    StreamScratch mem(stream);
+    PDSP_HIP_TRY(mem.alloc((planes * plane + extra) * sizeof(T)));
+    T *const scratch = (T *)mem.p;
     if (peaks_out && !amp) amp = scratch + planes * plane;
     if (peaks_out && !ph) ph = scratch + planes * plane + (amp_out ? 0 : rows);
     const int nyq = (sides == PDSP_SIDES_ONE) ? (int)(n / 2) : -1;
@@ -711,7 +726,6 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
                          peak_idx_out, batch);
       if (hipGetLastError() != hipSuccess) rc = fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
     }
-    (void)hipFreeAsync(scratch, stream);
     return rc;
   }
   constexpr uintptr_t kPairMask = 2 * sizeof(T) - 1;  // alignment of one (re, im) pair
@@ -770,8 +784,15 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     if (!t.tw) return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unaligned window at a size only the packed path holds");
     T *amp = amp_out, *ph = phase_out;
     const size_t row_bytes = (size_t)batch * bins * sizeof(T);
-    if (peaks_out && !amp) PDSP_HIP_TRY(hipMallocAsync((void **)&amp, row_bytes, stream));
-    if (peaks_out && !ph) PDSP_HIP_TRY(hipMallocAsync((void **)&ph, row_bytes, stream));
+    StreamScratch tmp_amp(stream), tmp_ph(stream);  // peaks-only output: the rows live in scratch
+    if (peaks_out && !amp) {
+      PDSP_HIP_TRY(tmp_amp.alloc(row_bytes));
+      amp = (T *)tmp_amp.p;
+    }
+    if (peaks_out && !ph) {
+      PDSP_HIP_TRY(tmp_ph.alloc(row_bytes));
+      ph = (T *)tmp_ph.p;
+    }
     pdsp::StoreAmplitude<T> st{amp, ph, bins,
                                // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
                                (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1, s_edge, s_mid};
@@ -786,8 +807,6 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph, bins,
                          freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
       PDSP_HIP_TRY(hipGetLastError());
-      if (!amp_out) PDSP_HIP_TRY(hipFreeAsync(amp, stream));
-      if (!phase_out) PDSP_HIP_TRY(hipFreeAsync(ph, stream));
     }
   }
   if (peak_idx_out) {
