@@ -402,7 +402,8 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   }
   hipError_t e;
   pdsp::StoreComplex<T> st{re_out, im_out, plan->n, scale};
-  if (plan->log2n >= 5 && plan->log2n <= 8 && g_staged_small &&
+  // (f64 at N = 256: 69.6 KB of LDS per workgroup, the direct kernel measures 12 % faster)
+  if (plan->log2n >= 5 && plan->log2n <= (sizeof(T) == 4 ? 8 : 7) && g_staged_small &&
       (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & (4 * sizeof(T) - 1)) == 0) {
     // small N: coalesced 16-byte I/O staged through LDS (fft_staged_kernel)
     const long long blocks = (batch * plan->n + 4095) / 4096;
@@ -735,7 +736,9 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     const bool fast = ((uintptr_t)frames & kPairMask) == 0 && (frame_stride & 1) == 0 && used == n &&
                       sides == PDSP_SIDES_ONE && phase_out == nullptr;
     // 64 <= N <= 512, amplitude only: contiguous frames staged in / amplitude rows staged out through LDS
-    if (fast && !peaks_out && !peak_idx_out && plan->log2n >= 6 && plan->log2n <= 9 && g_staged_small && frame_stride == n &&
+    // (f32 only: in f64 the two LDS regions take 102 KB, one workgroup per CU, and measure slower than the direct kernel)
+    if (sizeof(T) == 4 && fast && !peaks_out && !peak_idx_out && plan->log2n >= 6 && plan->log2n <= 9 && g_staged_small &&
+        frame_stride == n &&
         ((uintptr_t)frames & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)window & (4 * sizeof(T) - 1)) == 0) {
       const long long blocks = (batch * (n / 2) + 4095) / 4096;
 #define PDSP_SSTAGED(LM)                                                                                            \
