@@ -97,8 +97,10 @@ PDSP_API int pdsp_max_size(int scalar_bytes);
 /* Kernel selection switch for A/B tests (process-wide; returns the previous value): 1 (default)
  * runs whole aligned one-sided N = 16384 f32 spectra on spectrum_split16k_kernel (two 4096-point
  * sub-transforms per workgroup) and 16-byte aligned N = 16384 f32 complex/real rows on
- * fft_split4_kernel (four 4096-point sub-transforms per workgroup); 0 on spectrum_packed_kernel<13>
- * and fft_stockham_kernel<14>.  Same results within rounding. */
+ * fft_split4_kernel (four 4096-point sub-transforms per workgroup), and N = 8192 rows (f64; f32
+ * real input) on fft_split2_kernel; 0 on spectrum_packed_kernel<13> and the single-pass
+ * fft_stockham_kernel.  Same results within rounding.  (Bit 1 set also routes f32 complex
+ * N = 8192 rows to fft_split2_kernel: a development A/B switch.) */
 PDSP_API int pdsp_set_split16k(int enabled);
 /* Same kind of switch for 32 <= N <= 256 transforms on 16-byte aligned planes: 1 (default) =
  * fft_staged_kernel (the workgroup's contiguous 4096-point chunk staged through LDS with coalesced

@@ -1174,6 +1174,63 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   });
 }
 
+// The same cut one size down, as a radix-2 step: N = 8192 rows as two 4096-point transforms of the
+// same 256 threads (x[2m], x[2m+1] arrive in one 2-wide load per plane) and
+//   X[k] = E[k] + W_8192^k O[k],   X[k + 4096] = E[k] - W_8192^k O[k]    in registers.
+// This is the f64 kernel of the largest single-pass f64 size (fft_stockham_kernel<double, 13> holds
+// 139 KB of LDS, one workgroup per CU; here 69.6 KB, two), and with it the row pass of every f64
+// four-step transform.   tws[k] = W_8192^k, k < 256.
+template <typename T, class LD, class ST>
+__global__ void __launch_bounds__(256, 2)
+fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__restrict__ tw12,
+                  const typename vec2<T>::type *__restrict__ tws, const long long batch) {
+  using TR = FftTraits<12>;
+  constexpr int E = 16, TP = 256, H = 4096, N = 8192;
+  static_assert(LD::kPlanar && ST::kPlanar, "planar rows");
+  __shared__ cx<T> lds[TR::LROW];
+
+  const int tid = (int)threadIdx.x;
+  const long long row = uniform_row<TP>((long long)blockIdx.x);
+  if (row >= batch) return;
+
+  const cx<T> *const r2 = reinterpret_cast<const cx<T> *>(ld.plane_re() + (size_t)row * N);
+  cx<T> a[E], b[E];
+  if constexpr (LD::kHasIm) {
+    const cx<T> *const i2 = reinterpret_cast<const cx<T> *>(ld.plane_im() + (size_t)row * N);
+    static_for<E>([&](auto q) {
+      const cx<T> r = ld_stream(r2 + TP * q + (unsigned)tid);
+      const cx<T> m = ld_stream(i2 + TP * q + (unsigned)tid);
+      a[q] = cx<T>{r.x, m.x};
+      b[q] = cx<T>{r.y, m.y};
+    });
+  } else {
+    static_for<E>([&](auto q) {
+      const cx<T> r = ld_stream(r2 + TP * q + (unsigned)tid);
+      a[q] = cx<T>{r.x, T(0)};
+      b[q] = cx<T>{r.y, T(0)};
+    });
+  }
+  // f64 complex rows: 64 data registers + 24 twiddle-base registers + the butterfly's temporaries do not
+  // fit 256 VGPRs (81 spilled); reading the twiddles from the L2-resident table at each use instead
+  // measured 4.36 -> 5.80 TB/s.  f64 real rows fit (and measure 5.6 vs 5.35 with the bases in registers).
+  constexpr bool kTableTw = sizeof(T) == 8 && LD::kHasIm;
+  std::conditional_t<kTableTw, TableTwiddles<T, 12>, RegTwiddles<T, 12>> twf;
+  if constexpr (kTableTw) twf.tw = reinterpret_cast<const cx<T> *>(tw12);
+  else twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
+  const cx<T> w1 = reinterpret_cast<const cx<T> *>(tws)[(unsigned)tid];
+
+  fft_passes<T, 12, false>(a, lds, twf, tid);  // a[e] = E[tid + 256e]
+  __syncthreads();                            // the buffer is reused by the second transform
+  fft_passes<T, 12, false>(b, lds, twf, tid);  // b[e] = O[tid + 256e]
+
+  static_for<E>([&](auto ec) {
+    constexpr int e = ec;
+    const cx<T> t = cmul(b[e], mul_w32<T, e>(w1));  // W_8192^(tid + 256e) = w1 * W_32^e
+    st(row, TP * e, tid, a[e] + t);
+    st(row, H + TP * e, tid, a[e] - t);
+  });
+}
+
 // spectrum() body for N = 16384 real frames, the config-4 shape (whole 16-byte-aligned frames,
 // one-sided amplitude, optional fused findPeak), re-cut so that FOUR frames fit a CU.
 // The packed transform Z = FFT_8192(z), z[m] = x[2m] + i*x[2m+1], is taken as one radix-2

@@ -219,3 +219,42 @@ def test_split4_kernel_n16384_vs_single_pass_vs_oracle(pdsp, oracle_mod, batch):
     view.copy_(dre)
     ure, uim = plan.forward(view, dim)
     assert rel_err(ure.cpu().numpy().astype(np.float64) + 1j * uim.cpu().numpy(), wre + 1j * wim) <= TOL
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "float64"])
+def test_split2_kernel_n8192_vs_single_pass_vs_oracle(pdsp, oracle_mod, dtype_name):
+    """N = 8192 rows (f64; f32 real input; f32 complex with switch bit 1) run on fft_split2_kernel (two
+    4096-point sub-transforms + a radix-2 combine in registers); pdsp_set_split16k(0) routes the same
+    calls to fft_stockham_kernel<13>."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n, batch = 8192, 5
+    dt = getattr(torch, dtype_name)
+    npdt = np.float32 if dtype_name == "float32" else np.float64
+    tol = TOL if dtype_name == "float32" else 1e-13
+    rng = np.random.default_rng(8192)
+    re = rng.standard_normal((batch, n)).astype(npdt)
+    im = rng.standard_normal((batch, n)).astype(npdt)
+    plan = BatchedFft(n, "cuda:0", dtype=dt)
+    dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    rre, rim = oracle_mod.Plan(n).forward(re)
+    out = {}
+    for mode in (3, 0):
+        prev = pdsp.lib.pdsp_set_split16k(mode)
+        try:
+            guard = torch.full((batch + 2, n), 777.0, device="cuda", dtype=dt)
+            ore, oim = guard[1:batch + 1], torch.empty((batch, n), device="cuda", dtype=dt)
+            plan.forward(dre, dim, out=(ore, oim))
+            r2, i2 = plan.forward(dre)
+            b1, b2 = plan.inverse(ore, oim)
+            torch.cuda.synchronize()
+        finally:
+            pdsp.lib.pdsp_set_split16k(prev)
+        assert bool((guard[0] == 777.0).all()) and bool((guard[-1] == 777.0).all())
+        got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
+        assert rel_err(got, wre + 1j * wim) <= tol
+        assert rel_err(r2.cpu().numpy().astype(np.float64) + 1j * i2.cpu().numpy(), rre + 1j * rim) <= tol
+        assert rel_err(b1.cpu().numpy(), re) <= tol and rel_err(b2.cpu().numpy(), im) <= tol
+        out[mode] = got
+    assert rel_err(out[3], out[0]) <= (2e-6 if dtype_name == "float32" else 1e-14)
