@@ -186,12 +186,49 @@ def single_frame_latency(args, dev) -> int:
     return 0
 
 
+def stream_throughput(args, dev) -> int:
+    """The streaming front-end host-to-host: f64 frames in host memory ->
+    SpectrumResult objects, through pinned staging, H2D, the fused kernel, D2H and the host-side
+    findPeak.  PCIe- and host-bound: reported for DESIGN.md's PCIe-inclusive note, never as `value`
+    of the headline metric."""
+    import pragma_dsp_amd as pd
+    from pragma_dsp_amd.stream import SpectrumStream
+    rows = []
+    for n, frames in ((1024, 16384), (16384, 2048)):
+        rng = np.random.default_rng(n)
+        data = rng.standard_normal((frames, n))
+        for bits in (64, 32):
+            prev = pd.lib.pdsp_set_host_precision(bits)
+            try:
+                st = SpectrumStream({"sampleRate": 48000, "fftSize": n, "window": "hann"}, batch_frames=256, device=dev)
+                for f in data[:512]:
+                    st.push(f)
+                st.flush()
+                t0 = time.perf_counter()
+                got = 0
+                for f in data:
+                    got += len(st.push(f))
+                got += len(st.flush())
+                sec = time.perf_counter() - t0
+            finally:
+                pd.lib.pdsp_set_host_precision(prev)
+            assert got == frames
+            rows.append({"n": n, "precision": bits, "frames": frames, "frames_per_s": frames / sec,
+                         "GSample_per_s": frames * n / sec / 1e9, "us_per_frame": sec / frames * 1e6})
+    print(json.dumps({"metric": "SpectrumStream host-to-host throughput", "unit": "GSample/s", "higher_is_better": True,
+                      "value": max(r["GSample_per_s"] for r in rows), "n_gpus": 1, "steps": 1, "warmup": 1,
+                      "dtype": "f64/f32", "data": "synthetic",
+                      "config": {"workload": "spectrumStream(frames, {fftSize, hann}) from host f64 frames, batches of 256"},
+                      "rows": rows}), flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024", "stream"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -225,6 +262,8 @@ def main() -> int:
 
     if args.workload == "single1024":
         return single_frame_latency(args, dev)
+    if args.workload == "stream":
+        return stream_throughput(args, dev)
 
     if args.workload in ("spectrum16k", "peaks16k"):
         n, per_gpu = 16384, args.batch or (1 << 20)

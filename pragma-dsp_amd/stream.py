@@ -119,10 +119,11 @@ class SpectrumStream:
         if freqs is None:
             freqs = self._freqs[n] = binFrequencies(n, self.sample_rate, self.sides)
         out = []
+        # fresh f64 arrays per batch (the staging slot is reused); each result owns its rows of them
         amp64 = s.h_out[0, :s.count].numpy().astype(np.float64)
         ph64 = s.h_out[1, :s.count].numpy().astype(np.float64)
         for r in range(s.count):
-            a, p = amp64[r].copy(), ph64[r].copy()
+            a, p = amp64[r], ph64[r]
             k = int(lib.pdsp_find_peak_f64(dptr(a), len(a)))  # host findPeak, as in spectrum()
             out.append(SpectrumResult(freqs.copy(), a, p, SpectrumPeak(k, float(freqs[k]), float(a[k]), float(p[k]))))
         s.count = 0
