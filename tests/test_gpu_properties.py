@@ -258,3 +258,39 @@ def test_split2_kernel_n8192_vs_single_pass_vs_oracle(pdsp, oracle_mod, dtype_na
         assert rel_err(b1.cpu().numpy(), re) <= tol and rel_err(b2.cpu().numpy(), im) <= tol
         out[mode] = got
     assert rel_err(out[3], out[0]) <= (2e-6 if dtype_name == "float32" else 1e-14)
+
+
+@pytest.mark.parametrize("n", [64, 256, 1024, 4096, 16384, 65536])
+def test_nan_stays_in_its_own_row(oracle_mod, n):
+    """NaN/Inf propagate as in the reference (plain IEEE arithmetic), but only through the
+    row that holds them: rows share workgroups and LDS buffers in the batched kernels, so a poisoned
+    row must not leak into its neighbours.  findPeak on an all-NaN row is bin 0 (every `>` is false)."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    rng = np.random.default_rng(n)
+    batch = 9 if n <= 4096 else 3
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    bad = 1
+    x[bad, n // 3] = np.nan
+    plan = BatchedFft(n, "cuda:0")
+    dx = torch.from_numpy(x).cuda()
+    re, im = plan.forward(dx)
+    re, im = re.cpu().numpy(), im.cpu().numpy()
+    assert np.isnan(re[bad]).all() and np.isnan(im[bad]).all()
+    good = [b for b in range(batch) if b != bad]
+    wre, wim = oracle_mod.Plan(n).forward(x[good])
+    assert rel_err(re[good].astype(np.float64) + 1j * im[good], wre + 1j * wim) <= TOL
+    amp, _, pk = plan.spectrum(dx, "hann", "one", want_peak=True)
+    amp, pk = amp.cpu().numpy(), pk.cpu().numpy()
+    assert np.isnan(amp[bad]).all() and pk[bad] == 0
+    assert np.isfinite(amp[good]).all()
+    idx, _, pamp, _, _, _ = plan.spectrum_peaks(dx, "hann", "one", 48000.0)
+    assert int(idx[bad]) == 0 and np.isfinite(pamp.cpu().numpy()[good]).all()
+    wamp, _, wpk = oracle_mod.Plan(n).spectrum_batch(x[good], window=oracle_mod.create_window("hann", n).astype(np.float32),
+                                                     want_peak=True)
+    assert rel_err(amp[good], wamp) <= TOL
+    y = x.copy()
+    y[bad] = 0
+    y[bad, 5] = np.inf          # Inf - Inf appears inside the butterflies: the row turns non-finite, others do not
+    re, im = plan.forward(torch.from_numpy(y).cuda())
+    assert not np.isfinite(re.cpu().numpy()[bad]).any() and np.isfinite(re.cpu().numpy()[good]).all()
