@@ -230,6 +230,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024", "stream"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
+    ap.add_argument("--n", type=int, default=None, help="spectrum256 only: another frame size (development sweeps)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -270,7 +271,8 @@ def main() -> int:
     elif args.workload == "fft16k":
         n, per_gpu = 16384, args.batch or 16384  # 2^28 samples, as configs[2]
     elif args.workload == "spectrum256":
-        n, per_gpu = 256, args.batch or (1 << 22)
+        n = args.n or 256
+        per_gpu = args.batch or ((1 << 30) // n)
     else:
         n, per_gpu = 4096, args.batch or 65536
     # weak scaling: the global batch is per_gpu x world rows, split contiguously by rank
@@ -328,7 +330,7 @@ def main() -> int:
         bytes_per_launch = (4 * n + 4 * bins) * chunk  # 98,308 B per frame
         kernel_name = kernel_label = "spectrum_split16k_kernel<float, true, false>"
         if args.workload == "spectrum256":
-            kernel_name = kernel_label = "spectrum_staged_kernel<float, 7, true>"
+            kernel_name = kernel_label = "spectrum_staged_kernel<float, 7, true>" if n == 256 else f"spectrum kernel of N={n}"
         plan.window("hann")
 
         def step():
@@ -408,7 +410,7 @@ def main() -> int:
             "config": {"workload": {"fft4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex (configs[2])",
                                     "real4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forward fp32 real input",
                                     "fft16k": f"N=16384 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex",
-                                    "spectrum256": f"N=256 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude",
+                                    "spectrum256": f"N={n} batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude",
                                     "spectrum16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude (configs[3])",
                                     "peaks16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+findPeak, peaks-only output"}[args.workload],
                        "n": n, "batch_per_gpu": per_gpu, "global_batch": per_gpu * world,
