@@ -216,7 +216,7 @@ static int c16k_main(long long rows, int rounds) {
 }
 
 // HBM ceilings by read:write mix (argv: MiB rounds mix): float4 grid-stride kernels, non-temporal
-template <int R, int W>
+template <int R, int W, bool SCALAR_ST = false>
 __global__ void __launch_bounds__(256) mix_kernel(const float4 *__restrict__ in_, float4 *__restrict__ out_, size_t n4) {
   typedef float V4 __attribute__((ext_vector_type(4)));
   const V4 *in = reinterpret_cast<const V4 *>(in_);
@@ -227,23 +227,29 @@ __global__ void __launch_bounds__(256) mix_kernel(const float4 *__restrict__ in_
     for (int r = 0; r < R; ++r) acc += __builtin_nontemporal_load(in + (size_t)r * n4 + i);
     if (W == 0) {
       if (acc.x == 12345.678f) out[0] = acc;  // never true: keeps the loads alive
+    } else if (SCALAR_ST) {
+      // dword stores, unit stride across the lanes (the FFT kernels' store shape): 4 per float4
+      float *o = reinterpret_cast<float *>(out);
+      const size_t blk = (i / 64) * 256, lane = i % 64;
+      for (int w = 0; w < W; ++w)
+        for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[j], o + (size_t)w * n4 * 4 + blk + 64 * j + lane);
     } else {
       for (int w = 0; w < W; ++w) __builtin_nontemporal_store(acc, out + (size_t)w * n4 + i);
     }
   }
 }
 
-template <int R, int W>
+template <int R, int W, bool SCALAR_ST = false>
 static void mix_run(const float4 *in, float4 *out, size_t n4, int rounds, int grid) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<float> ms;
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((mix_kernel<R, W>), dim3(grid), dim3(256), 0, 0, in, out, n4);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((mix_kernel<R, W, SCALAR_ST>), dim3(grid), dim3(256), 0, 0, in, out, n4);
   CK(hipDeviceSynchronize());
   for (int r = 0; r < rounds; ++r) {
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((mix_kernel<R, W>), dim3(grid), dim3(256), 0, 0, in, out, n4);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((mix_kernel<R, W, SCALAR_ST>), dim3(grid), dim3(256), 0, 0, in, out, n4);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float t;
@@ -252,7 +258,7 @@ static void mix_run(const float4 *in, float4 *out, size_t n4, int rounds, int gr
   }
   std::sort(ms.begin(), ms.end());
   const double bytes = 16.0 * n4 * (R + W);
-  printf("mix read:write %d:%d grid %5d  med %.4f ms  %.0f GB/s (max %.0f)\n", R, W, grid, ms[ms.size() / 2],
+  printf("mix read:write %d:%d%s grid %5d  med %.4f ms  %.0f GB/s (max %.0f)\n", R, W, SCALAR_ST ? " (dword stores)" : "", grid, ms[ms.size() / 2],
          bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
 }
 
@@ -266,6 +272,8 @@ static int mix_main(long long mib, int rounds) {
     mix_run<1, 0>(in, out, n4 * 4, rounds, grid);
     mix_run<1, 1>(in, out, n4 * 2, rounds, grid);
     mix_run<2, 1>(in, out, n4 * 2, rounds, grid);
+    mix_run<2, 1, true>(in, out, n4 * 2, rounds, grid);
+    mix_run<1, 1, true>(in, out, n4 * 2, rounds, grid);
     mix_run<4, 1>(in, out, n4, rounds, grid);
     mix_run<1, 2>(in, out, n4, rounds, grid);
   }
