@@ -160,6 +160,14 @@ PDSP_API int pdsp_fft_forward_real_f32(const pdsp_plan *plan, long long batch,
 PDSP_API int pdsp_fft_forward_complex_f32(const pdsp_plan *plan, long long batch,
                                           const float *re_in, const float *im_in,
                                           float *re_out, float *im_out, pdsp_stream stream);
+/* The same forwardComplex / inverse on INTERLEAVED rows: in/out hold batch*N (re, im) pairs
+ * (2*N scalars per row) -- the layout of I/Q streams and complex64 tensors.  An extension: the
+ * reference's ComplexArray is planar (src/core/fft.ts:1-4).  Single-pass sizes only (N <= 16384
+ * in f32, 8192 in f64; PDSP_ERR_UNSUPPORTED_SIZE beyond); out may alias in row for row. */
+PDSP_API int pdsp_fft_forward_interleaved_f32(const pdsp_plan *plan, long long batch, const float *in,
+                                              float *out, pdsp_stream stream);
+PDSP_API int pdsp_fft_inverse_interleaved_f32(const pdsp_plan *plan, long long batch, const float *in,
+                                              float *out, pdsp_stream stream);
 /* Radix2Fft.inverse (conjugate twiddles + 1/N), src/core/fft.ts:85-87, :142-148. */
 PDSP_API int pdsp_fft_inverse_f32(const pdsp_plan *plan, long long batch,
                                   const float *re_in, const float *im_in,
@@ -240,6 +248,10 @@ PDSP_API int pdsp_fft_forward_complex_f64(const pdsp_plan *plan, long long batch
 PDSP_API int pdsp_fft_inverse_f64(const pdsp_plan *plan, long long batch,
                                   const double *re_in, const double *im_in,
                                   double *re_out, double *im_out, pdsp_stream stream);
+PDSP_API int pdsp_fft_forward_interleaved_f64(const pdsp_plan *plan, long long batch, const double *in,
+                                              double *out, pdsp_stream stream);
+PDSP_API int pdsp_fft_inverse_interleaved_f64(const pdsp_plan *plan, long long batch, const double *in,
+                                              double *out, pdsp_stream stream);
 PDSP_API int pdsp_apply_window_f64(long long batch, long long n, const double *in,
                                    const double *window, double *out, pdsp_stream stream);
 PDSP_API int pdsp_magnitude_f64(long long count, const double *re, const double *im,

@@ -84,6 +84,8 @@ def _load() -> C.CDLL:
         "pdsp_fft_forward_real_f32": ([vp, ll, vp, vp, vp, vp], i32),
         "pdsp_fft_forward_complex_f32": ([vp, ll, vp, vp, vp, vp, vp], i32),
         "pdsp_fft_inverse_f32": ([vp, ll, vp, vp, vp, vp, vp], i32),
+        "pdsp_fft_forward_interleaved_f32": ([vp, ll, vp, vp, vp], i32),
+        "pdsp_fft_inverse_interleaved_f32": ([vp, ll, vp, vp, vp], i32),
         "pdsp_apply_window_f32": ([ll, ll, vp, vp, vp, vp], i32),
         "pdsp_magnitude_f32": ([ll, vp, vp, vp, vp], i32),
         "pdsp_phase_f32": ([ll, vp, vp, vp, vp], i32),
@@ -92,6 +94,8 @@ def _load() -> C.CDLL:
         "pdsp_fft_forward_real_f64": ([vp, ll, vp, vp, vp, vp], i32),
         "pdsp_fft_forward_complex_f64": ([vp, ll, vp, vp, vp, vp, vp], i32),
         "pdsp_fft_inverse_f64": ([vp, ll, vp, vp, vp, vp, vp], i32),
+        "pdsp_fft_forward_interleaved_f64": ([vp, ll, vp, vp, vp], i32),
+        "pdsp_fft_inverse_interleaved_f64": ([vp, ll, vp, vp, vp], i32),
         "pdsp_apply_window_f64": ([ll, ll, vp, vp, vp, vp], i32),
         "pdsp_magnitude_f64": ([ll, vp, vp, vp, vp], i32),
         "pdsp_phase_f64": ([ll, vp, vp, vp, vp], i32),

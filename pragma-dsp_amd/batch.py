@@ -110,6 +110,25 @@ class BatchedFft:
                                                           _stream_ptr(self.device)))
         return ore, oim
 
+    def forward_interleaved(self, z: torch.Tensor, out: torch.Tensor | None = None, inverse: bool = False):
+        """forwardComplex (or inverse) on rows of a complex64 / complex128 tensor [..., N] -- the
+        interleaved (re, im) layout of I/Q streams.  Single-pass sizes only."""
+        want = torch.complex64 if self.dtype == torch.float32 else torch.complex128
+        if z.dtype != want or not z.is_cuda or not z.is_contiguous() or z.device != self.device:
+            raise PdspError(_capi.ERR_BAD_ARG, f"input must be a contiguous {want} tensor on {self.device}")
+        if z.shape[-1] != self.size:
+            raise PdspError(_capi.ERR_INPUT_LENGTH, f"FFT input length {z.shape[-1]} != size {self.size}")
+        if out is None:
+            out = torch.empty_like(z)
+        elif out.dtype != want or out.shape != z.shape or not out.is_contiguous() or out.device != self.device:
+            raise PdspError(_capi.ERR_BAD_ARG, "out must match the input's dtype, shape and device")
+        fn = getattr(lib, ("pdsp_fft_inverse_interleaved_" if inverse else "pdsp_fft_forward_interleaved_") + self._sfx)
+        check(fn(self._h, z.numel() // self.size, _ptr(z), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def inverse_interleaved(self, z: torch.Tensor, out: torch.Tensor | None = None):
+        return self.forward_interleaved(z, out, inverse=True)
+
     def spectrum(self, frames: torch.Tensor, window="rect", sides: str = "one", want_phase: bool = False,
                  want_peak: bool = False, out=None):
         """Rows of spectrum()'s body: frames [..., L] (L <= N zero-padded, L > N

@@ -452,6 +452,34 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   return PDSP_OK;
 }
 
+// Interleaved complex rows (single-pass sizes): forward, or inverse = conj . forward . conj with 1/N.
+template <typename T>
+int run_interleaved(const pdsp_plan *plan, long long batch, const T *in, T *out, bool inverse, hipStream_t s) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (batch == 0) return PDSP_OK;
+  if (!in || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  if ((((uintptr_t)in | (uintptr_t)out) & (2 * sizeof(T) - 1)) != 0)
+    return fail(PDSP_ERR_BAD_ARG, "interleaved rows must be aligned to one (re, im) pair");
+  const Tables<T> &t = tables<T>(plan);
+  if (!t.tw || t.log2n1 > 0)
+    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "interleaved rows are single-pass only: FFT size %lld exceeds %d", plan->n,
+                1 << max_log2n<T>());
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  const pdsp::cx<T> *zin = reinterpret_cast<const pdsp::cx<T> *>(in);
+  pdsp::cx<T> *zout = reinterpret_cast<pdsp::cx<T> *>(out);
+  if (inverse) {
+    pdsp::LoadInterleaved<T, true> ld{zin, plan->n};
+    pdsp::StoreInterleaved<T, true> st{zout, plan->n, T(1) / (T)plan->n};
+    PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s));
+  } else {
+    pdsp::LoadInterleaved<T, false> ld{zin, plan->n};
+    pdsp::StoreInterleaved<T, false> st{zout, plan->n, T(1)};
+    PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s));
+  }
+  return PDSP_OK;
+}
+
 int grid_for(long long total) {
   long long b = (total + 255) / 256;
   if (b > 2048) b = 2048;  // grid-stride the rest (256 CUs x 8)
@@ -1154,6 +1182,14 @@ int pdsp_plan_device(const pdsp_plan *plan) { return plan ? plan->device : -1; }
     if (!plan) return fail(PDSP_ERR_BAD_ARG, "plan is null");                                                      \
     if (batch > 0 && !re_in) return fail(PDSP_ERR_BAD_ARG, "null buffer");                                         \
     return run_complex<T>(plan, batch, im_in, re_in, im_out, re_out, T(1) / (T)plan->n, (hipStream_t)stream);      \
+  }                                                                                                                \
+  int pdsp_fft_forward_interleaved_##SUFFIX(const pdsp_plan *plan, long long batch, const T *in, T *out,           \
+                                            pdsp_stream stream) {                                                  \
+    return run_interleaved<T>(plan, batch, in, out, false, (hipStream_t)stream);                                   \
+  }                                                                                                                \
+  int pdsp_fft_inverse_interleaved_##SUFFIX(const pdsp_plan *plan, long long batch, const T *in, T *out,           \
+                                            pdsp_stream stream) {                                                  \
+    return run_interleaved<T>(plan, batch, in, out, true, (hipStream_t)stream);                                    \
   }                                                                                                                \
   int pdsp_apply_window_##SUFFIX(long long batch, long long n, const T *in, const T *window, T *out,               \
                                  pdsp_stream stream) {                                                             \

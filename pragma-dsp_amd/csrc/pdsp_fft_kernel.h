@@ -252,6 +252,34 @@ struct LoadReal {  // Radix2Fft.forward: imaginary part is zero
   __device__ __forceinline__ const T *plane_im() const { return nullptr; }
 };
 
+// Interleaved (re, im) rows -- the layout of I/Q streams and of complex64 tensors; one 8-byte
+// access per point.  CONJ turns the forward kernel into the inverse: conj on the way in and out.
+template <typename T, bool CONJ>
+struct LoadInterleaved {
+  const cx<T> *__restrict__ z;
+  long long n;
+  __device__ __forceinline__ cx<T> operator()(long long row, int off, int lane) const {
+    cx<T> v = ld_stream(z + (size_t)row * (size_t)n + (size_t)off + (unsigned)lane);
+    if constexpr (CONJ) v.y = -v.y;
+    return v;
+  }
+  static constexpr bool kPlanar = false;
+  static constexpr bool kHasIm = true;
+};
+
+template <typename T, bool CONJ>
+struct StoreInterleaved {
+  cx<T> *__restrict__ z;
+  long long n;
+  T scale;
+  __device__ __forceinline__ void operator()(long long row, int off, int lane, cx<T> v) const {
+    v = v * scale;
+    if constexpr (CONJ) v.y = -v.y;
+    st_stream(v, z + (size_t)row * (size_t)n + (size_t)off + (unsigned)lane);
+  }
+  static constexpr bool kPlanar = false;
+};
+
 // Loads are unconditional (clamped address + select): a per-element `if` around a
 // load makes hipcc branch and drain vmcnt per element (cdna guide, section 5 item 4c).
 template <typename T, bool HAS_WIN>

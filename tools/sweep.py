@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 F64 = "--f64" in sys.argv  # the f64 device family (bytes double, sizes up to 8192 single-pass / 16384 spectrum)
 DT = torch.float64 if F64 else torch.float32
 SZ = 8 if F64 else 4
-print(f"{'N':>6} {'C2C GB/s':>10} {'frac':>6} {'real GB/s':>10} {'frac':>6} {'spec GB/s':>10} {'frac':>6} {'spec(direct)':>12} {'C2C(direct)':>12}")
+print(f"{'N':>6} {'C2C GB/s':>10} {'frac':>6} {'real GB/s':>10} {'frac':>6} {'spec GB/s':>10} {'frac':>6} {'spec(direct)':>12} {'C2C(direct)':>12} {'interleaved':>12}")
 for log2n in range(6, 14 if F64 else 15):
     n = 1 << log2n
     batch = (1 << 27) // n  # 2^27 complex points: 1 GiB in + 1 GiB out for C2C
@@ -40,9 +40,13 @@ for log2n in range(6, 14 if F64 else 15):
     prev = _capi.lib.pdsp_set_staged_small(0)
     t_s0 = timed(lambda: plan.spectrum(re, "hann", "one", out=amp))
     t_c0 = timed(lambda: plan.forward(re, im, out=(ore, oim)))
+    zi = torch.complex(re, im)
+    zo = torch.empty_like(zi)
+    t_i = timed(lambda: plan.forward_interleaved(zi, out=zo))
+    del zi, zo
     _capi.lib.pdsp_set_staged_small(prev)
     c = 4.0 * SZ * batch * n / t_c / 1e9
     r = 3.0 * SZ * batch * n / t_r / 1e9
     s = SZ * (n + (n // 2 + 1)) * batch / t_s / 1e9
-    print(f"{n:6d} {c:10.0f} {c/8000:6.3f} {r:10.0f} {r/8000:6.3f} {s:10.0f} {s/8000:6.3f} {s*t_s/t_s0:12.0f} {c*t_c/t_c0:12.0f}", flush=True)
+    print(f"{n:6d} {c:10.0f} {c/8000:6.3f} {r:10.0f} {r/8000:6.3f} {s:10.0f} {s/8000:6.3f} {s*t_s/t_s0:12.0f} {c*t_c/t_c0:12.0f} {c*t_c/t_i:12.0f}", flush=True)
     del re, im, ore, oim, amp, plan
