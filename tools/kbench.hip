@@ -280,7 +280,85 @@ static int mix_main(long long mib, int rounds) {
   return 0;
 }
 
+// XCD-locality probe (argv: rows rounds xcd): the N=4096 C2C kernel with the workgroup -> row map
+//   row = 8P*g + P*((xcd + c) % 8) + j,   xcd = blockIdx % 8, j = (blockIdx % 8P) / 8, g = blockIdx / 8P
+// i.e. every run of P consecutive rows goes to one XCD, rotated by c.  If HBM stacks have an affinity
+// to XCDs, some (P, c) stands out.
+template <int P>
+__global__ void __launch_bounds__(256)
+fft_remap_kernel(const float *__restrict__ re, const float *__restrict__ im, float *__restrict__ ore,
+                 float *__restrict__ oim, const float2 *__restrict__ tw, const int c, const long long batch) {
+  using namespace pdsp;
+  using TR = FftTraits<12>;
+  constexpr int E = 16, TP = 256;
+  __shared__ cx<float> lds[TR::LDS_ELEMS];
+  const int tid = (int)threadIdx.x;
+  const long long b = blockIdx.x;
+  const long long g = b / (8 * P);
+  const int w = (int)(b % (8 * P)), xcd = w % 8, j = w / 8;
+  const long long row = uniform_row<TP>(g * (8 * P) + P * ((xcd + c) % 8) + j);
+  LoadComplex<float> ld{re, im, 4096};
+  StoreComplex<float> st{ore, oim, 4096, 1.0f};
+  cx<float> x[E];
+  static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
+  RegTwiddles<float, 12> twf;
+  twf.load(reinterpret_cast<const cx<float> *>(tw), tid);
+  fft_passes<float, 12, false>(x, lds, twf, tid);
+  static_for<E>([&](auto q) { st(row, TP * q, tid, x[q]); });
+}
+
+template <int P>
+static void xcd_run(const float *re, const float *im, float *ore, float *oim, const float2 *dtw, long long batch, int rounds) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  printf("P=%2d:", P);
+  for (int c = 0; c < 8; ++c) {
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fft_remap_kernel<P>), dim3(batch), dim3(256), 0, 0, re, im, ore, oim, dtw, c, batch);
+    CK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < rounds; ++r) {
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fft_remap_kernel<P>), dim3(batch), dim3(256), 0, 0, re, im, ore, oim, dtw, c, batch);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float t;
+      CK(hipEventElapsedTime(&t, e0, e1));
+      best = std::min(best, t / 5);
+    }
+    printf(" %5.0f", 16.0 * batch * 4096 / best / 1e6);
+  }
+  printf("  GB/s for c = 0..7\n");
+}
+
+static int xcd_main(long long batch, int rounds) {
+  const size_t cnt = (size_t)batch * 4096;
+  float *re, *im, *ore, *oim;
+  CK(hipMalloc(&re, cnt * 4));
+  CK(hipMalloc(&im, cnt * 4));
+  CK(hipMalloc(&ore, cnt * 4));
+  CK(hipMalloc(&oim, cnt * 4));
+  CK(hipMemset(re, 0, cnt * 4));
+  CK(hipMemset(im, 0, cnt * 4));
+  std::vector<float2> tw;
+  fill_tw(12, tw);
+  float2 *dtw;
+  CK(hipMalloc(&dtw, tw.size() * 8));
+  CK(hipMemcpy(dtw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+  printf("planes at %p %p %p %p\n", (void *)re, (void *)im, (void *)ore, (void *)oim);
+  for (int rep = 0; rep < 2; ++rep) {
+    xcd_run<1>(re, im, ore, oim, dtw, batch, rounds);
+    xcd_run<2>(re, im, ore, oim, dtw, batch, rounds);
+    xcd_run<4>(re, im, ore, oim, dtw, batch, rounds);
+    xcd_run<8>(re, im, ore, oim, dtw, batch, rounds);
+    xcd_run<16>(re, im, ore, oim, dtw, batch, rounds);
+    xcd_run<64>(re, im, ore, oim, dtw, batch, rounds);
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 3 && std::string(argv[3]) == "xcd") return xcd_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "mix") return mix_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "c16k") return c16k_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "spec") return spec_main(atoll(argv[1]), atoi(argv[2]));
