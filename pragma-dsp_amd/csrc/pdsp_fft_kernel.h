@@ -32,17 +32,6 @@
 
 #include "pdsp_radix.h"
 
-// Option: sub-transforms of the split kernels run pairwise through two LDS rows (fft_passes_pair:
-// shared barriers, read-backs in flight together).  Off: measured in the library on one box it is
-// slower for fft_split4_kernel (C2C 5.41 vs 5.94 TB/s, real-in 4.91 vs 5.81) and -1 % for
-// spectrum_split16k_kernel, although the standalone micro-benchmark had shown +3..5 %.
-#ifndef PDSP_SPLIT4_PAIRED
-#define PDSP_SPLIT4_PAIRED 0
-#endif
-#ifndef PDSP_SPLIT16K_PAIRED
-#define PDSP_SPLIT16K_PAIRED 0
-#endif
-
 namespace pdsp {
 
 // Diagnostic build only (tools/kbench -DPDSP_STAMPS): wave 0 of each workgroup adds the shader
@@ -506,26 +495,6 @@ __device__ __forceinline__ void fft_passes(cx<T> (&x)[EE], cx<T> *const lrow, co
       // the next pass writes LDS again (every pass but a register-resident last one)
       if constexpr (p + 1 < NP - 1 || LAST_TO_LDS) __syncthreads();
       PDSP_STAMP(10 + 4 * p);  // LDS read-back issued + barrier
-    }
-  });
-}
-
-// Two independent transforms of the same threads, pass by pass through two LDS rows: the pair
-// shares every barrier and its LDS read-backs are in flight together (half the exposed round
-// trips of running fft_passes twice).
-template <typename T, int LOG2N, bool LAST_TO_LDS, int LOG2E = 4, class TWF = void, int EE = 0>
-__device__ __forceinline__ void fft_passes_pair(cx<T> (&x0)[EE], cx<T> (&x1)[EE], cx<T> *const l0, cx<T> *const l1,
-                                                const TWF &twf, const int tid) {
-  constexpr int NP = FftTraits<LOG2N, LOG2E>::NP;
-  static_for<NP>([&](auto pc) {
-    constexpr int p = pc;
-    fft_pass_compute<T, LOG2N, LAST_TO_LDS, LOG2E, p>(x0, l0, twf, tid);
-    fft_pass_compute<T, LOG2N, LAST_TO_LDS, LOG2E, p>(x1, l1, twf, tid);
-    if constexpr (p != NP - 1) {
-      __syncthreads();
-      fft_pass_readback<T, LOG2N, LOG2E>(x0, l0, tid);
-      fft_pass_readback<T, LOG2N, LOG2E>(x1, l1, tid);
-      if constexpr (p + 1 < NP - 1 || LAST_TO_LDS) __syncthreads();
     }
   });
 }
@@ -1142,7 +1111,7 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   static_assert(LD::kPlanar && ST::kPlanar, "planar rows");
   static_assert(TP >= 64 && TP % 64 == 0, "whole waves per row");
   typedef T V4 __attribute__((ext_vector_type(4)));
-  __shared__ cx<T> lds[(PDSP_SPLIT4_PAIRED ? 2 : 1) * TR::LROW];
+  __shared__ cx<T> lds[TR::LROW];
 
   const int tid = (int)threadIdx.x;
   const long long row = uniform_row<TP>((long long)blockIdx.x);
@@ -1174,11 +1143,6 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
   const cx<T> w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
 
-#if PDSP_SPLIT4_PAIRED
-  fft_passes_pair<T, LOG2S, false>(a, b, lds, lds + TR::LROW, twf, tid);  // a[e] = F0[tid + TP*e], b[e] = F1[..]
-  __syncthreads();                                                       // the buffers are reused by the next pair
-  fft_passes_pair<T, LOG2S, false>(c, d, lds, lds + TR::LROW, twf, tid);
-#else
   fft_passes<T, LOG2S, false>(a, lds, twf, tid);  // a[e] = F0[tid + TP*e]
   __syncthreads();                               // the buffer is reused by the next transform
   fft_passes<T, LOG2S, false>(b, lds, twf, tid);
@@ -1186,7 +1150,6 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   fft_passes<T, LOG2S, false>(c, lds, twf, tid);
   __syncthreads();
   fft_passes<T, LOG2S, false>(d, lds, twf, tid);
-#endif
 
   // radix-4 combine; W_N^{j(tid + TP*e)} = wj * W_64^{je}  (N = 64*TP)
   static_for<E>([&](auto ec) {
@@ -1283,7 +1246,7 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
   using TR = FftTraits<12>;
   constexpr int E = 16, TP = 256, H = 4096, M = 8192;
   typedef T V4 __attribute__((ext_vector_type(4)));
-  __shared__ cx<T> lds[(PDSP_SPLIT16K_PAIRED ? 2 : 1) * TR::LROW];
+  __shared__ cx<T> lds[TR::LROW];
 
   const int tid = (int)threadIdx.x;
   const long long row = uniform_row<TP>((long long)blockIdx.x);
@@ -1319,14 +1282,10 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
   pin_regs<T, E>(b);
 #endif
   PDSP_STAMP(32);  // wait for the frame + window loads
-#if PDSP_SPLIT16K_PAIRED
-  fft_passes_pair<T, 12, false>(a, b, lds, lds + TR::LROW, twf, tid);  // a[q] = Ev[tid + 256q], b[q] = Od[tid + 256q]
-#else
   fft_passes<T, 12, false>(a, lds, twf, tid);  // a[q] = Ev[tid + 256q]
   __syncthreads();                            // the buffer is reused by the second transform
   PDSP_STAMP(33);  // first sub-transform
   fft_passes<T, 12, false>(b, lds, twf, tid);  // b[q] = Od[tid + 256q]
-#endif
   PDSP_STAMP(34);  // second sub-transform
 
   // radix-2 combine in registers: a <- Z[k], b <- Z[k + 4096]
