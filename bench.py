@@ -371,6 +371,22 @@ def main() -> int:
 
     elapsed = max_over_ranks(elapsed, dev)
 
+    # context for the roofline fraction (outside the timed region): the rate at which this box, with
+    # these very buffers, copies the input planes to the output planes (torch's device copy kernel)
+    copy_gbps = None
+    if args.workload in ("fft4096", "fft16k") and rank == 0:
+        for _ in range(3):
+            ore.copy_(re)
+            oim.copy_(im)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(10):
+            ore.copy_(re)
+            oim.copy_(im)
+        c1.record(stream)
+        torch.cuda.synchronize(dev)
+        copy_gbps = 10 * bytes_per_launch / (c0.elapsed_time(c1) * 1e-3) / 1e9
+
     gather = None
     if args.gather and world > 1 and args.workload in ("fft4096", "real4096"):
         # the one exchange step of the path: RCCL all-gather of the output slabs,
@@ -420,6 +436,7 @@ def main() -> int:
                          # PMC bytes of the committed rocprofv3 passes: only valid for the profiled shape
                          "traffic": traffic_from_profile(kernel_name) if args.batch is None and args.chunk == 16384 else None,
                          "kernel": kernel_label,
+                         "device_copy_same_buffers_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launch_ms_avg": launch_ms, "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
         }
