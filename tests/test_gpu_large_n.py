@@ -105,3 +105,23 @@ def test_general_four_step_spectrum_aliasing_and_dropin(pdsp, oracle_mod):
     w = oracle_mod.spectrum(sig, sample_rate=48000, window="hann")
     assert len(g.amplitude) == (1 << 19) + 1 and g.peak.index == w["peak"]["index"]
     assert np.abs(g.amplitude - w["amplitude"]).max() <= 1e-12
+
+
+def test_general_four_step_n_2_24(oracle_mod):
+    """N = 2^24 = 1024 x 16384 (f32) and 2048 x 8192 (f64): larger N1 than the other cases exercise."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 1 << 24
+    rng = np.random.default_rng(24)
+    re = rng.standard_normal((1, n))
+    im = rng.standard_normal((1, n))
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    want = wre + 1j * wim
+    for dt, npdt, tol in ((torch.float32, np.float32, 1e-5), (torch.float64, np.float64, 1e-13)):
+        plan = BatchedFft(n, "cuda:0", dtype=dt)
+        dre, dim = torch.from_numpy(re.astype(npdt)).cuda(), torch.from_numpy(im.astype(npdt)).cuda()
+        ore, oim = plan.forward(dre, dim)
+        assert rel_err(ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy(), want) <= tol
+        bre, bim = plan.inverse(ore, oim)
+        assert rel_err(bre.cpu().numpy(), re) <= tol and rel_err(bim.cpu().numpy(), im) <= tol
+        del plan, dre, dim, ore, oim, bre, bim
