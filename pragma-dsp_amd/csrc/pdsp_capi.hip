@@ -336,6 +336,25 @@ int fourstep_c(const pdsp_plan *plan, long long batch, const T *s_re, const T *s
   return PDSP_OK;
 }
 
+// fft_staged_kernel on planar complex rows of 32 <= N <= 256 points (16-byte aligned planes).
+template <typename T>
+hipError_t launch_staged_complex(int log2n, const pdsp::LoadComplex<T> &ld, const pdsp::StoreComplex<T> &st,
+                                 const typename pdsp::vec2<T>::type *tw, long long rows, hipStream_t s) {
+  const long long blocks = ((rows << log2n) + 4095) / 4096;
+#define PDSP_STAGED_C(L)                                                                                  \
+  hipLaunchKernelGGL((pdsp::fft_staged_kernel<T, L, pdsp::LoadComplex<T>, pdsp::StoreComplex<T>>),         \
+                     dim3((unsigned)blocks), dim3(256), 0, s, ld, st, tw, rows)
+  switch (log2n) {
+    case 5: PDSP_STAGED_C(5); break;
+    case 6: PDSP_STAGED_C(6); break;
+    case 7: PDSP_STAGED_C(7); break;
+    case 8: PDSP_STAGED_C(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef PDSP_STAGED_C
+  return hipGetLastError();
+}
+
 // General four-step path (log2n1 > kMaxLog2N1), steps 1-4 of bigfft_transpose_kernel's header:
 // transposes `in` into (a_re, a_im) = [n2][n1], N1-point rows in place, twiddled transpose into
 // (b_re, b_im) = [k1][n2], N2-point rows in place.  Step 5 is bigfft_out.
@@ -354,6 +373,8 @@ int bigfft_rows(const pdsp_plan *plan, long long batch, const T *re_in, const T 
     pdsp::LoadComplex<T> ld{a_re, a_im, n1};
     pdsp::StoreComplex<T> st{a_re, a_im, n1, T(1)};
     if (t.log2n1 == t.log2n2) PDSP_HIP_TRY(launch_rows<T>(t, t.log2n1, ld, st, batch << t.log2n2, s, true));
+    else if (t.log2n1 <= (sizeof(T) == 4 ? 8 : 7) && g_staged_small)  // short rows: the staged kernel's coalesced I/O
+      PDSP_HIP_TRY(launch_staged_complex<T>(t.log2n1, ld, st, t.tw1, batch << t.log2n2, s));
     else PDSP_HIP_TRY(launch_fft<T>(t.log2n1, ld, st, t.tw1, batch << t.log2n2, s));
   }
   hipLaunchKernelGGL((pdsp::bigfft_transpose_kernel<T, true, false>), dim3((unsigned)tiles), dim3(256), 0, s, a_re, a_im,
