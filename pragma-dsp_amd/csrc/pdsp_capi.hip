@@ -355,6 +355,31 @@ hipError_t launch_staged_complex(int log2n, const pdsp::LoadComplex<T> &ld, cons
   return hipGetLastError();
 }
 
+// fft_tiny_staged_kernel for 2 <= N <= 16 (one thread per row, chunk staged through LDS).
+template <typename T, bool AMP, class LD>
+hipError_t launch_tiny(int log2n, const LD &ld, const T *win, T *o1, T *o2, T scale, int bins, int nyq, T s_edge,
+                       T s_mid, long long batch, hipStream_t s) {
+  const long long blocks = ((batch << log2n) + 4095) / 4096;
+#define PDSP_TINY(L)                                                                                             \
+  hipLaunchKernelGGL((pdsp::fft_tiny_staged_kernel<T, L, AMP, LD>), dim3((unsigned)blocks), dim3(256), 0, s, ld, win, \
+                     o1, o2, scale, bins, nyq, s_edge, s_mid, batch)
+  switch (log2n) {
+    case 1: PDSP_TINY(1); break;
+    case 2: PDSP_TINY(2); break;
+    case 3: PDSP_TINY(3); break;
+    case 4: PDSP_TINY(4); break;
+    case 5:
+      if constexpr (AMP) {  // N = 32 transforms have fft_staged_kernel; the spectrum of N = 32 frames comes here
+        PDSP_TINY(5);
+        break;
+      }
+      return hipErrorInvalidValue;
+    default: return hipErrorInvalidValue;
+  }
+#undef PDSP_TINY
+  return hipGetLastError();
+}
+
 // General four-step path (log2n1 > kMaxLog2N1), steps 1-4 of bigfft_transpose_kernel's header:
 // transposes `in` into (a_re, a_im) = [n2][n1], N1-point rows in place, twiddled transpose into
 // (b_re, b_im) = [k1][n2], N2-point rows in place.  Step 5 is bigfft_out.
@@ -433,6 +458,19 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
     return rc;
   }
   hipError_t e;
+  const bool planes16 =
+      (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & (4 * sizeof(T) - 1)) == 0;
+  if (plan->log2n >= 1 && plan->log2n <= 4 && g_staged_small && planes16) {  // 2 <= N <= 16: one thread per row
+    if (im_in) {
+      pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};
+      e = launch_tiny<T, false>(plan->log2n, ld, (const T *)nullptr, re_out, im_out, scale, 0, 0, T(0), T(0), batch, s);
+    } else {
+      pdsp::LoadReal<T> ld{re_in, plan->n};
+      e = launch_tiny<T, false>(plan->log2n, ld, (const T *)nullptr, re_out, im_out, scale, 0, 0, T(0), T(0), batch, s);
+    }
+    PDSP_HIP_TRY(e);
+    return PDSP_OK;
+  }
   pdsp::StoreComplex<T> st{re_out, im_out, plan->n, scale};
   // (f64 at N = 256: 69.6 KB of LDS per workgroup, the direct kernel measures 12 % faster)
   if (plan->log2n >= 5 && plan->log2n <= (sizeof(T) == 4 ? 8 : 7) && g_staged_small &&
@@ -858,6 +896,19 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
   } else {
     // complex kernel on (x, 0) for N < 64 or an unaligned window; peaks come from the stored rows
     if (!t.tw) return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unaligned window at a size only the packed path holds");
+    if (plan->log2n >= 1 && plan->log2n <= 5 && g_staged_small && used == n && frame_stride == n && amp_out &&
+        !phase_out && !peaks_out && ((uintptr_t)frames & (4 * sizeof(T) - 1)) == 0) {
+      // 2 <= N <= 32, whole contiguous frames, amplitude only: one thread per frame, chunk staged through LDS
+      pdsp::LoadReal<T> ld{frames, n};
+      PDSP_HIP_TRY((launch_tiny<T, true>(plan->log2n, ld, window, amp_out, (T *)nullptr, T(1), bins,
+                                         sides == PDSP_SIDES_ONE ? (int)(n / 2) : -1, s_edge, s_mid, batch, stream)));
+      if (peak_idx_out) {
+        hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
+                           peak_idx_out, batch);
+        PDSP_HIP_TRY(hipGetLastError());
+      }
+      return PDSP_OK;
+    }
     T *amp = amp_out, *ph = phase_out;
     const size_t row_bytes = (size_t)batch * bins * sizeof(T);
     StreamScratch tmp_amp(stream), tmp_ph(stream);  // peaks-only output: the rows live in scratch

@@ -132,12 +132,15 @@ __device__ __forceinline__ cx<T> mul_w16(const cx<T> a) {
   }
 }
 
-// In-register radix-R DFT (R = 2, 4, 8, 16) as log2 R decimation-in-frequency
+template <typename T, int NUM>
+__device__ __forceinline__ cx<T> mul_w32(const cx<T> a);
+
+// In-register radix-R DFT (R = 2, 4, 8, 16; 32 for whole tiny rows) as log2 R decimation-in-frequency
 // radix-2 stages -- each one a stage of the reference's loop nest
 // (src/core/fft.ts:116-140) with a compile-time twiddle.  Output k lands in slot bitrev(k).
 template <typename T, int R>
 __device__ __forceinline__ void fft_reg(cx<T> (&a)[R]) {
-  static_assert(R >= 1 && R <= 16 && (R & (R - 1)) == 0, "radix");
+  static_assert(R >= 1 && R <= 32 && (R & (R - 1)) == 0, "radix");
   static_for<ilog2(R)>([&](auto stc) {
     constexpr int s = R >> (stc + 1);  // half length of this stage's sub-transforms
     static_for<R / 2>([&](auto ic) {
@@ -145,7 +148,7 @@ __device__ __forceinline__ void fft_reg(cx<T> (&a)[R]) {
       constexpr int i0 = g + k, i1 = i0 + s;
       const cx<T> u = a[i0], v = a[i1];
       a[i0] = u + v;
-      a[i1] = mul_w16<T, k *(8 / s)>(u - v);  // W_{2s}^k
+      a[i1] = mul_w32<T, k *(16 / s)>(u - v);  // W_{2s}^k (even multiples resolve to the W16 forms)
     });
   });
 }
@@ -622,6 +625,107 @@ fft_staged_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
       st_stream(V4{v0.y, v1.y, v2.y, v3.y}, reinterpret_cast<V4 *>(st.im + g));
     }
   });
+}
+
+// Tiny transforms (2 <= N <= 16; the amplitude spectrum also N = 32): one thread owns a whole row, so in the direct kernel a lane's
+// accesses are N*4 bytes apart (N = 16 measured 4 % of the HBM roofline).  Same cure as
+// fft_staged_kernel: the workgroup's 4096-point chunk goes through LDS with coalesced 16-byte
+// accesses on both sides; each thread transforms 16/N rows out of LDS in registers (fft_reg).
+//   AMP = false: planar complex rows out (times st.scale) -- forward / forwardComplex / inverse.
+//   AMP = true:  real frames (whole, contiguous) times an optional window in, one- or two-sided
+//                amplitude rows of `bins` values out (the body of spectrum(), complex kernel on (x*w, 0)).
+template <typename T, int LOG2N, bool AMP, class LD>
+__global__ void __launch_bounds__(256)
+fft_tiny_staged_kernel(const LD ld, const T *__restrict__ win, T *__restrict__ o1, T *__restrict__ o2, const T scale,
+                       const int bins, const int nyq, const T s_edge, const T s_mid, const long long batch) {
+  constexpr int N = 1 << LOG2N, WG = 256, CHUNK = 4096, ROWS = CHUNK / N, RPT = ROWS >= WG ? ROWS / WG : 1;
+  static_assert(LOG2N >= 1 && LOG2N <= 5, "tiny path: 2 <= N <= 32 (N = 32: half the threads hold a row)");
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[CHUNK + CHUNK / 16];
+  const int t = (int)threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * CHUNK;
+  const size_t limit = (size_t)batch * N;  // points per plane
+  const T *const pre = ld.plane_re();
+  const T *const pim = ld.plane_im();
+
+  static_for<CHUNK / 4 / WG>([&](auto ic) {
+    const int p = 4 * (t + WG * ic);
+    size_t g = base + (size_t)p;
+    if (limit >= 4) g = g + 4 <= limit ? g : limit - 4;  // the tail workgroup re-reads valid points
+    V4 r, m = V4{T(0), T(0), T(0), T(0)};
+    if (limit >= 4) {
+      r = ld_stream(reinterpret_cast<const V4 *>(pre + g));
+      if constexpr (LD::kHasIm) m = ld_stream(reinterpret_cast<const V4 *>(pim + g));
+    } else {  // a single N = 2 row: two points in all
+      r = V4{pre[0], pre[1], T(0), T(0)};
+      if constexpr (LD::kHasIm) m = V4{pim[0], pim[1], T(0), T(0)};
+    }
+    if constexpr (N == 2) {
+      // an odd number of 2-point rows: the group that straddles the end was read two points early
+      const size_t g0 = base + (size_t)p;
+      if (limit >= 4 && g0 < limit && g0 + 4 > limit) {
+        r = V4{r.z, r.w, T(0), T(0)};
+        m = V4{m.z, m.w, T(0), T(0)};
+      }
+    }
+    cx<T> *const d = lds + lds_pad(p);
+    d[0] = cx<T>{r.x, m.x};
+    d[1] = cx<T>{r.y, m.y};
+    d[2] = cx<T>{r.z, m.z};
+    d[3] = cx<T>{r.w, m.w};
+  });
+  __syncthreads();
+
+  cx<T> x[RPT][N];
+  const bool holds_row = ROWS >= WG || t < ROWS;
+  static_for<RPT>([&](auto rc) {
+    const int row = holds_row ? t + WG * rc : ROWS - 1;  // local row; its points are lds[pad(row*N + q)]
+    static_for<N>([&](auto q) {
+      cx<T> v = lds[lds_pad(row * N + q)];
+      if constexpr (AMP) {
+        if (win) v = v * win[q];  // uniform across the lanes: scalar loads
+      }
+      x[rc][q] = v;
+    });
+    fft_reg<T, N>(x[rc]);  // X[k] in slot bitrev(k)
+  });
+  __syncthreads();  // every thread has its inputs: the buffer now takes the outputs
+
+  if constexpr (!AMP) {
+    static_for<RPT>([&](auto rc) {
+      const int row = t + WG * rc;
+      if (holds_row) static_for<N>([&](auto k) { lds[lds_pad(row * N + k)] = x[rc][bitrev(k, LOG2N)] * scale; });
+    });
+    __syncthreads();
+    static_for<CHUNK / 4 / WG>([&](auto ic) {
+      const int p = 4 * (t + WG * ic);
+      const size_t g = base + (size_t)p;
+      const cx<T> *const d = lds + lds_pad(p);
+      if (g + 4 <= limit) {
+        st_stream(V4{d[0].x, d[1].x, d[2].x, d[3].x}, reinterpret_cast<V4 *>(o1 + g));
+        st_stream(V4{d[0].y, d[1].y, d[2].y, d[3].y}, reinterpret_cast<V4 *>(o2 + g));
+      } else if (g < limit) {  // N = 2, odd tail: fewer than four points left
+        for (int j = 0; j < 4 && g + j < limit; ++j) {
+          o1[g + j] = d[j].x;
+          o2[g + j] = d[j].y;
+        }
+      }
+    });
+  } else {
+    T *const ampf = reinterpret_cast<T *>(lds);  // ROWS rows of `bins` <= N amplitudes: at most 4096 values
+    static_for<RPT>([&](auto rc) {
+      const int row = t + WG * rc;
+      static_for<N>([&](auto k) {
+        if (holds_row && k < bins)
+          ampf[row * bins + k] = mag(x[rc][bitrev(k, LOG2N)]) * ((k == 0 || k == nyq) ? s_edge : s_mid);
+      });
+    });
+    __syncthreads();
+    const size_t out_base = (size_t)blockIdx.x * ROWS * (size_t)bins, out_limit = (size_t)batch * (size_t)bins;
+    const int out_count = ROWS * bins;
+    for (int i = t; i < out_count; i += WG)
+      if (out_base + (size_t)i < out_limit) o1[out_base + (size_t)i] = ampf[i];
+  }
 }
 
 // Fused body of spectrum() for real frames, one frame per row, via the packed-real

@@ -294,3 +294,58 @@ def test_nan_stays_in_its_own_row(oracle_mod, n):
     y[bad, 5] = np.inf          # Inf - Inf appears inside the butterflies: the row turns non-finite, others do not
     re, im = plan.forward(torch.from_numpy(y).cuda())
     assert not np.isfinite(re.cpu().numpy()[bad]).any() and np.isfinite(re.cpu().numpy()[good]).all()
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32])
+@pytest.mark.parametrize("batch", [1, 3, 127, 128, 129, 255, 256, 257, 2049, 5000])
+def test_tiny_staged_kernel_vs_direct_vs_oracle(pdsp, oracle_mod, n, batch):
+    """2 <= N <= 16 on 16-byte aligned planes runs on fft_tiny_staged_kernel (one thread per row, the
+    workgroup's chunk staged through LDS) for transforms and for whole-frame amplitude spectra (those
+    also at N = 32, where the transforms take fft_staged_kernel);
+    pdsp_set_staged_small(0) routes the same calls to the direct kernels.  Odd batches of N = 2 rows
+    exercise the group that straddles the end of the plane."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    rng = np.random.default_rng(16 * n + batch)
+    re = rng.standard_normal((batch, n)).astype(np.float32)
+    im = rng.standard_normal((batch, n)).astype(np.float32)
+    plan = BatchedFft(n, "cuda:0")
+    dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+    o = oracle_mod.Plan(n)
+    wre, wim = o.forward_complex(re, im)
+    rre, rim = o.forward(re)
+    win = oracle_mod.create_window("hamming", n).astype(np.float32)
+    res = {}
+    for mode in (1, 0):
+        prev = pdsp.lib.pdsp_set_staged_small(mode)
+        try:
+            guard = torch.full((batch + 2, n), 777.0, device="cuda")
+            ore, oim = guard[1:batch + 1], torch.empty((batch, n), device="cuda")
+            plan.forward(dre, dim, out=(ore, oim))
+            r2, i2 = plan.forward(dre)
+            b1, b2 = plan.inverse(ore, oim)
+            amps = {}
+            for sides in ("one", "two"):
+                bins = n // 2 + 1 if sides == "one" else n
+                abuf = torch.full((batch * bins + 32,), -7.0, device="cuda")
+                aout = abuf[:batch * bins].view(batch, bins)
+                _, _, pk = plan.spectrum(dre, "hamming", sides, want_peak=True, out=aout)
+                torch.cuda.synchronize()
+                assert bool((abuf[batch * bins:] == -7.0).all())
+                amps[sides] = (aout.cpu().numpy().astype(np.float64), pk.cpu().numpy())
+            torch.cuda.synchronize()
+        finally:
+            pdsp.lib.pdsp_set_staged_small(prev)
+        assert bool((guard[0] == 777.0).all()) and bool((guard[-1] == 777.0).all())
+        got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
+        assert rel_err(got, wre + 1j * wim) <= TOL
+        assert rel_err(r2.cpu().numpy().astype(np.float64) + 1j * i2.cpu().numpy(), rre + 1j * rim) <= TOL
+        assert rel_err(b1.cpu().numpy(), re) <= TOL and rel_err(b2.cpu().numpy(), im) <= TOL
+        for sides in ("one", "two"):
+            wamp, _, wpk = o.spectrum_batch(re, window=win, two_sided=(sides == "two"), want_peak=True)
+            a, pk = amps[sides]
+            assert a.shape == wamp.shape and rel_err(a, wamp) <= TOL
+            for b in range(batch):
+                assert abs(wamp[b, pk[b]] - wamp[b, wpk[b]]) <= 2 * TOL * wamp[b].max()
+        res[mode] = got
+    assert rel_err(res[1], res[0]) <= 2e-6
