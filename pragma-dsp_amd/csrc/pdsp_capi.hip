@@ -355,6 +355,23 @@ hipError_t launch_staged_complex(int log2n, const pdsp::LoadComplex<T> &ld, cons
   return hipGetLastError();
 }
 
+// findPeak over stored amplitude rows: index array and/or SpectrumPeak records.
+template <typename T>
+hipError_t launch_peaks(const T *amp, const T *ph, int bins, T freq_scale, int32_t *peak_idx, pdsp_peak32 *peaks,
+                        long long batch, hipStream_t s) {
+  pdsp::PeakRec *recs = reinterpret_cast<pdsp::PeakRec *>(peaks);
+  if (bins <= 2048) {  // one wave per row
+    hipLaunchKernelGGL((pdsp::peak_wave_kernel<T>), dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, amp, ph, bins,
+                       freq_scale, peak_idx, recs, batch);
+    return hipGetLastError();
+  }
+  if (peak_idx) hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, s, amp, bins, peak_idx, batch);
+  if (recs)
+    hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, s, amp, ph, bins, freq_scale,
+                       recs, batch);
+  return hipGetLastError();
+}
+
 // fft_tiny_staged_kernel for 2 <= N <= 16 (one thread per row, chunk staged through LDS).
 template <typename T, bool AMP, class LD>
 hipError_t launch_tiny(int log2n, const LD &ld, const T *win, T *o1, T *o2, T scale, int bins, int nyq, T s_edge,
@@ -828,16 +845,9 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       rc = fourstep_ab<T>(plan, batch, frames, nullptr, window, frame_stride, used, scratch, scratch + plane, stream);
       if (!rc) rc = fourstep_c<T, 1>(plan, batch, scratch, scratch + plane, amp, ph, T(1), bins, nyq, s_edge, s_mid, stream);
     }
-    if (!rc && peaks_out) {
-      hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph, bins,
-                         freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
-      if (hipGetLastError() != hipSuccess) rc = fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
-    }
-    if (!rc && peak_idx_out) {
-      hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
-                         peak_idx_out, batch);
-      if (hipGetLastError() != hipSuccess) rc = fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
-    }
+    if (!rc && (peaks_out || peak_idx_out) &&
+        launch_peaks<T>(amp, ph, bins, freq_scale, peak_idx_out, peaks_out, batch, stream) != hipSuccess)
+      rc = fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
     return rc;
   }
   constexpr uintptr_t kPairMask = 2 * sizeof(T) - 1;  // alignment of one (re, im) pair
@@ -902,11 +912,8 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       pdsp::LoadReal<T> ld{frames, n};
       PDSP_HIP_TRY((launch_tiny<T, true>(plan->log2n, ld, window, amp_out, (T *)nullptr, T(1), bins,
                                          sides == PDSP_SIDES_ONE ? (int)(n / 2) : -1, s_edge, s_mid, batch, stream)));
-      if (peak_idx_out) {
-        hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
-                           peak_idx_out, batch);
-        PDSP_HIP_TRY(hipGetLastError());
-      }
+      if (peak_idx_out)
+        PDSP_HIP_TRY(launch_peaks<T>(amp_out, (const T *)nullptr, bins, T(0), peak_idx_out, nullptr, batch, stream));
       return PDSP_OK;
     }
     T *amp = amp_out, *ph = phase_out;
@@ -930,17 +937,10 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       pdsp::LoadFrameWindowed<T, false> ld{frames, window, used, frame_stride};
       PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, stream));
     }
-    if (peaks_out) {
-      hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp, ph, bins,
-                         freq_scale, reinterpret_cast<pdsp::PeakRec *>(peaks_out), batch);
-      PDSP_HIP_TRY(hipGetLastError());
-    }
+    if (peaks_out) PDSP_HIP_TRY(launch_peaks<T>(amp, ph, bins, freq_scale, nullptr, peaks_out, batch, stream));
   }
-  if (peak_idx_out) {
-    hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, amp_out, bins,
-                       peak_idx_out, batch);
-    PDSP_HIP_TRY(hipGetLastError());
-  }
+  if (peak_idx_out)
+    PDSP_HIP_TRY(launch_peaks<T>(amp_out, (const T *)nullptr, bins, T(0), peak_idx_out, nullptr, batch, stream));
   return PDSP_OK;
 }
 

@@ -1634,4 +1634,48 @@ find_peak_kernel(const T *__restrict__ amp, int bins, int *__restrict__ peak, lo
   if (threadIdx.x == 0) peak[row] = si[0];
 }
 
+// Short rows (bins <= 2048): one WAVE per row, four rows per workgroup -- no LDS, no barriers, and
+// a launch of `batch/4` workgroups instead of `batch` (N = 64: the workgroup-per-row form took
+// 14x the time of the spectrum kernel it follows).  Same rules as find_peak_kernel /
+// peak_from_rows_kernel; `ph` and `peaks` may be null / `peak` may be null (one of the outputs is set).
+template <typename T>
+__global__ void __launch_bounds__(256)
+peak_wave_kernel(const T *__restrict__ amp, const T *__restrict__ ph, int bins, T freq_scale, int *__restrict__ peak,
+                 PeakRec *__restrict__ peaks, long long batch) {
+  const int lane = (int)threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (row >= batch) return;
+  const T *a = amp + (size_t)row * (size_t)bins;
+  T bv = T(0);
+  int bi = 0;
+  for (int i = 1 + lane; i < bins; i += 64) {
+    const T v = a[i];
+    if (v > bv) {  // strict: the earliest index wins inside a lane's stride
+      bv = v;
+      bi = i;
+    }
+  }
+  static_for<6>([&](auto sc) {
+    constexpr int off = 32 >> sc;
+    const T ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    // larger value wins; equal values: smaller index (first-wins); index 0 = "none"
+    if (ov > bv || (ov == bv && oi != 0 && (bi == 0 || oi < bi))) {
+      bv = ov;
+      bi = oi;
+    }
+  });
+  if (lane == 0) {
+    if (peak) peak[row] = bi;
+    if (peaks) {
+      PeakRec r;
+      r.index = bi;
+      r.frequency = (float)(T(bi) * freq_scale);
+      r.amplitude = (float)a[bi];
+      r.phase = ph ? (float)ph[(size_t)row * (size_t)bins + bi] : 0.0f;
+      peaks[row] = r;
+    }
+  }
+}
+
 }  // namespace pdsp
