@@ -210,6 +210,10 @@ PDSP_API int pdsp_complex_op_f32(int op, long long count, const float *a_re, con
  * (:45-72) [-> phase, :122,128-131] [-> findPeak index, :74-105].
  *   frames      [batch][frame_stride] real samples; the first
  *               min(frame_len, N) of each row are used, the rest is zero.
+ *               frame_stride >= 1: a stride below frame_len reads OVERLAPPING frames of one
+ *               signal (a short-time transform with hop = frame_stride; frame b starts at
+ *               sample b*frame_stride and the buffer must hold (batch-1)*frame_stride +
+ *               min(frame_len, N) samples).
  *   window      N device floats, or NULL for "rect".
  *   amp_out     [batch][bins], bins = N/2+1 (one-sided) or N (two-sided).
  *   phase_out   same shape, or NULL.

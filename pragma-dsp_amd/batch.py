@@ -158,6 +158,32 @@ class BatchedFft:
         return amp, ph, pk
 
 
+    def stft(self, signal: torch.Tensor, hop: int, window="hann", sides: str = "one", want_phase: bool = False,
+             want_peak: bool = False):
+        """Short-time transform of one contiguous 1-D signal: frame b = signal[b*hop : b*hop + N], the
+        body of spectrum() on every frame.  The frames are never materialised -- the kernels read the
+        signal with row stride `hop`, so overlapping frames cost no extra HBM footprint.  Returns
+        (amplitude [frames, bins], phase or None, peak bin or None)."""
+        if signal.dim() != 1 or signal.dtype != self.dtype or not signal.is_cuda or not signal.is_contiguous():
+            raise PdspError(_capi.ERR_BAD_ARG, f"signal must be a contiguous 1-D {self.dtype} CUDA tensor")
+        if hop < 1:
+            raise PdspError(_capi.ERR_BAD_ARG, f"hop must be >= 1, got {hop}")
+        n = self.size
+        if signal.numel() < n:
+            raise PdspError(_capi.ERR_INPUT_LENGTH, f"signal length {signal.numel()} is shorter than one frame ({n})")
+        frames = 1 + (signal.numel() - n) // hop
+        two = sides != "one"
+        bins = n if two else n // 2 + 1
+        if self.size != 1 and window not in _capi.WINDOW_TYPES:
+            raise PdspError(_capi.ERR_WINDOW_TYPE, f"Unsupported window type: {window}")
+        win = None if (window == "rect" or n == 1) else self.window(window)
+        amp = torch.empty((frames, bins), dtype=self.dtype, device=self.device)
+        ph = torch.empty((frames, bins), dtype=self.dtype, device=self.device) if want_phase else None
+        pk = torch.empty((frames,), dtype=torch.int32, device=self.device) if want_peak else None
+        check(getattr(lib, "pdsp_spectrum_" + self._sfx)(self._h, frames, _ptr(signal), n, int(hop), _ptr(win), 1 if two else 0,
+                                                         _ptr(amp), _ptr(ph), _ptr(pk), _stream_ptr(self.device)))
+        return amp, ph, pk
+
     def spectrum_peaks(self, frames: torch.Tensor, window="rect", sides: str = "one", sample_rate: float = 1.0,
                        want_amp: bool = False, want_phase: bool = False):
         """Rows of the whole spectrum() tail on the device: one SpectrumPeak per frame

@@ -800,7 +800,8 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
                   double sample_rate, hipStream_t stream) {
   if (int rc = check_plan_batch(plan, batch)) return rc;
   if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
-  if (frame_len < 0 || frame_stride < frame_len) return fail(PDSP_ERR_BAD_ARG, "bad frame_len/frame_stride");
+  // frame_stride < frame_len = overlapping frames of one signal (an STFT with hop = frame_stride): rows are only read
+  if (frame_len < 0 || frame_stride < 1) return fail(PDSP_ERR_BAD_ARG, "bad frame_len/frame_stride");
   if (peaks_out && sample_rate <= 0)
     return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
   if (batch == 0) return PDSP_OK;
