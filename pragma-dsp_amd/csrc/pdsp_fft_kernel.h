@@ -105,10 +105,42 @@ template <typename T>
 __device__ __forceinline__ cx<T> conj(const cx<T> a) {
   return cx<T>{a.x, -a.y};
 }
-// a * w = a.re*(w.re, w.im) + a.im*(-w.im, w.re): one pk_mul + one pk_fma
+// a + (-i)*b = (a.re + b.im, a.im - b.re)  and  a + i*b = (a.re - b.im, a.im + b.re).
+// For f32 the half swap and the sign ride on the op_sel / neg modifiers of ONE v_pk_add_f32; hipcc does
+// not find that form by itself (it materialises (-i)*b with a v_xor + v_mov first: 21 % of the N=16384
+// spectrum kernel's vector instructions were such pairs), hence the inline asm.
+template <typename T>
+__device__ __forceinline__ cx<T> add_mul_neg_i(const cx<T> a, const cx<T> b) {
+  if constexpr (std::is_same_v<T, float>) {
+    cx<float> r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  } else {
+    return cx<T>{a.x + b.y, a.y - b.x};
+  }
+}
+template <typename T>
+__device__ __forceinline__ cx<T> add_mul_pos_i(const cx<T> a, const cx<T> b) {
+  if constexpr (std::is_same_v<T, float>) {
+    cx<float> r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  } else {
+    return cx<T>{a.x - b.y, a.y + b.x};
+  }
+}
+// a * w = a.re*(w.re, w.im) + a.im*(-w.im, w.re): one pk_mul + one pk_fma (f32: spelled out for the
+// same reason -- the second product's swapped, half-negated operand is an op_sel / neg_lo pattern)
 template <typename T>
 __device__ __forceinline__ cx<T> cmul(const cx<T> a, const cx<T> w) {
-  return a.xx * w + a.yy * cx<T>{-w.y, w.x};
+  if constexpr (std::is_same_v<T, float>) {
+    cx<float> t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+  } else {
+    return a.xx * w + a.yy * cx<T>{-w.y, w.x};
+  }
 }
 
 // a * W16^M,  W16 = e^{-2*pi*i/16},  0 <= M < 8.
@@ -122,9 +154,9 @@ __device__ __forceinline__ cx<T> mul_w16(const cx<T> a) {
   } else if constexpr (M == 4) {  // -i
     return mul_neg_i(a);
   } else if constexpr (M == 2) {  // (1 - i)/sqrt2: (re + im, im - re) * C2
-    return (a + mul_neg_i(a)) * C2;
-  } else if constexpr (M == 6) {  // (-1 - i)/sqrt2: (im - re, -re - im) * C2
-    return (mul_neg_i(a) - a) * C2;
+    return add_mul_neg_i(a, a) * C2;
+  } else if constexpr (M == 6) {  // (-1 - i)/sqrt2 = -(1 + i)/sqrt2: -(re - im, im + re) * C2
+    return add_mul_pos_i(a, a) * (-C2);
   } else {
     constexpr T c = M == 1 ? C1 : M == 3 ? C3 : M == 5 ? -C3 : -C1;
     constexpr T s = M == 1 ? -C3 : M == 3 ? -C1 : M == 5 ? -C1 : -C3;  // W = c + i*s
@@ -138,9 +170,61 @@ __device__ __forceinline__ cx<T> mul_w32(const cx<T> a);
 // In-register radix-R DFT (R = 2, 4, 8, 16; 32 for whole tiny rows) as log2 R decimation-in-frequency
 // radix-2 stages -- each one a stage of the reference's loop nest
 // (src/core/fft.ts:116-140) with a compile-time twiddle.  Output k lands in slot bitrev(k).
+// Radix-4 DIF butterfly on four registers, outputs in natural order y0..y3.  The two odd outputs are
+// (x0 - x2) -/+ i (x1 - x3): one fused add each, no materialised rotation.
+template <typename T>
+__device__ __forceinline__ void bfly4(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3) {
+  const cx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = add_mul_neg_i(t1, t3);
+  a3 = add_mul_pos_i(t1, t3);
+}
+// The same with input x2 still carrying a pending factor -i (x2 = -i * d): t0 = x0 - i d, t1 = x0 + i d.
+template <typename T>
+__device__ __forceinline__ void bfly4_x2_rot(cx<T> &a0, cx<T> &a1, cx<T> &d, cx<T> &a3) {
+  const cx<T> t0 = add_mul_neg_i(a0, d), t1 = add_mul_pos_i(a0, d), t2 = a1 + a3, t3 = a1 - a3;
+  a0 = t0 + t2;
+  d = t0 - t2;
+  a1 = add_mul_neg_i(t1, t3);
+  a3 = add_mul_pos_i(t1, t3);
+}
+
 template <typename T, int R>
 __device__ __forceinline__ void fft_reg(cx<T> (&a)[R]) {
   static_assert(R >= 1 && R <= 32 && (R & (R - 1)) == 0, "radix");
+  if constexpr (R == 4) {
+    bfly4(a[0], a[1], a[2], a[3]);  // X[q] in slot q; bitrev order wants X[1] <-> X[2] swapped
+    const cx<T> x1 = a[1];
+    a[1] = a[2];
+    a[2] = x1;
+    return;
+  } else if constexpr (R == 16) {
+    // two radix-4 stages: 64 fused adds + 8 twiddle products, no rotation is ever materialised.
+    // Stage A over stride 4: y_q of column j lands in a[j + 4q], then times W16^(j*q).
+    static_for<4>([&](auto jc) {
+      constexpr int j = jc;
+      bfly4(a[j], a[j + 4], a[j + 8], a[j + 12]);
+      if constexpr (j > 0) {
+        a[j + 4] = mul_w32<T, 2 * j>(a[j + 4]);                           // W16^j
+        if constexpr (j != 2) a[j + 8] = mul_w32<T, (4 * j) % 32>(a[j + 8]);  // W16^2j (j = 2: the -i stays pending)
+        a[j + 12] = mul_w32<T, (6 * j) % 32>(a[j + 12]);                  // W16^3j
+      }
+    });
+    // Stage B on each group of four: X[q + 4*q2] lands in a[4q + q2]
+    bfly4(a[0], a[1], a[2], a[3]);
+    bfly4(a[4], a[5], a[6], a[7]);
+    bfly4_x2_rot(a[8], a[9], a[10], a[11]);  // a[10] = y_2 of column 2, still to be multiplied by W16^4 = -i
+    bfly4(a[12], a[13], a[14], a[15]);
+    // callers expect output k in slot bitrev(k, 4)
+    cx<T> o[16];
+    static_for<16>([&](auto kc) {
+      constexpr int k = kc;
+      o[bitrev(k, 4)] = a[4 * (k & 3) + (k >> 2)];
+    });
+    static_for<16>([&](auto kc) { a[kc] = o[kc]; });
+    return;
+  }
   static_for<ilog2(R)>([&](auto stc) {
     constexpr int s = R >> (stc + 1);  // half length of this stage's sub-transforms
     static_for<R / 2>([&](auto ic) {
@@ -830,10 +914,9 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       if constexpr (LOG2E == 4) w = mul_w32<T, q>(twk0);   // N = 32*TP: W_N^(TP*q) = W32^q
       else w = (reinterpret_cast<const cx<T> *>(twr) + TP * q)[(unsigned)tid];
       const cx<T> e = (z + conj(zp)) * T(0.5);             // E
-      const cx<T> o = mul_neg_i(z - conj(zp)) * T(0.5);    // O = (Z - conj Zp)/(2i)
-      const cx<T> t = cmul(o, w);
-      const cx<T> xa = e + t;                              // X[k]
-      const cx<T> xb = conj(e - t);                        // X[M-k]
+      const cx<T> p = cmul(z - conj(zp), w) * T(0.5);      // i * O * W, O = (Z - conj Zp)/(2i)
+      const cx<T> xa = add_mul_neg_i(e, p);                // X[k] = E + W*O
+      const cx<T> xb = conj(add_mul_pos_i(e, p));          // X[M-k] = conj(E - W*O)
       // bins 0 (DC, from k = 0) and M (Nyquist, the partner of k = 0) are not doubled
       const T sc = (k == 0) ? s_edge : s_mid;
       const T ma = mag(xa) * sc, mb = mag(xb) * sc;
@@ -1154,11 +1237,10 @@ spectrum_staged_kernel(const T *__restrict__ frames, const T *__restrict__ win,
       const cx<T> z = lrow[lds_pad(k)], zp = lrow[lds_pad(k2 & (M - 1))];
       const cx<T> w = mul_w32<T, q>(twk0);  // W_N^k: N = 32*TP
       const cx<T> e = (z + conj(zp)) * T(0.5);
-      const cx<T> o = mul_neg_i(z - conj(zp)) * T(0.5);
-      const cx<T> tt = cmul(o, w);
-      const T sc = (k == 0) ? s_edge : s_mid;  // DC and Nyquist are not doubled
-      arow[k] = mag(e + tt) * sc;
-      if (k2 != k) arow[k2] = mag(conj(e - tt)) * sc;
+      const cx<T> p = cmul(z - conj(zp), w) * T(0.5);  // i * W * O
+      const T sc = (k == 0) ? s_edge : s_mid;          // DC and Nyquist are not doubled
+      arow[k] = mag(add_mul_neg_i(e, p)) * sc;
+      if (k2 != k) arow[k2] = mag(add_mul_pos_i(e, p)) * sc;  // |conj(.)| = |.|
     }
   });
   __syncthreads();
@@ -1261,11 +1343,11 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
     const cx<T> t1 = cmul(b[e], mul_w64<T, e>(w1));
     const cx<T> t2 = cmul(c[e], mul_w64<T, (2 * e) % 64>(w2));
     const cx<T> t3 = cmul(d[e], mul_w64<T, (3 * e) % 64>(w3));
-    const cx<T> s0 = a[e] + t2, s1 = a[e] - t2, s2 = t1 + t3, s3 = mul_neg_i(t1 - t3);
+    const cx<T> s0 = a[e] + t2, s1 = a[e] - t2, s2 = t1 + t3, d13 = t1 - t3;
     st(row, 0 * H + TP * e, tid, s0 + s2);
-    st(row, 1 * H + TP * e, tid, s1 + s3);
+    st(row, 1 * H + TP * e, tid, add_mul_neg_i(s1, d13));  // s1 - i (t1 - t3)
     st(row, 2 * H + TP * e, tid, s0 - s2);
-    st(row, 3 * H + TP * e, tid, s1 - s3);
+    st(row, 3 * H + TP * e, tid, add_mul_pos_i(s1, d13));  // s1 + i (t1 - t3)
   });
 }
 
@@ -1424,10 +1506,9 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
     else zp = *(uhi - cpad(TP * q));
     const cx<T> w = mul_w64<T, q>(ws0);                  // W_N^k
     const cx<T> e = (z + conj(zp)) * T(0.5);
-    const cx<T> o = mul_neg_i(z - conj(zp)) * T(0.5);
-    const cx<T> t = cmul(o, w);
-    const cx<T> xa = e + t;                              // X[k]
-    const cx<T> xb = conj(e - t);                        // X[8192 - k]
+    const cx<T> p = cmul(z - conj(zp), w) * T(0.5);      // i * W * O, O = (Z - conj Zp)/(2i)
+    const cx<T> xa = add_mul_neg_i(e, p);                // X[k] = E + W*O
+    const cx<T> xb = conj(add_mul_pos_i(e, p));          // X[8192 - k] = conj(E - W*O)
     const T sc = (k == 0) ? s_edge : s_mid;              // DC and Nyquist are not doubled
     const T ma = mag(xa) * sc, mb = mag(xb) * sc;
     if constexpr (PEAK) {
