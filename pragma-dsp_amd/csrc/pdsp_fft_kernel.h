@@ -1236,11 +1236,12 @@ spectrum_staged_kernel(const T *__restrict__ frames, const T *__restrict__ win,
       const int k = tid + TP * q, k2 = M - k;
       const cx<T> z = lrow[lds_pad(k)], zp = lrow[lds_pad(k2 & (M - 1))];
       const cx<T> w = mul_w32<T, q>(twk0);  // W_N^k: N = 32*TP
-      const cx<T> e = (z + conj(zp)) * T(0.5);
-      const cx<T> p = cmul(z - conj(zp), w) * T(0.5);  // i * W * O
-      const T sc = (k == 0) ? s_edge : s_mid;          // DC and Nyquist are not doubled
-      arow[k] = mag(add_mul_neg_i(e, p)) * sc;
-      if (k2 != k) arow[k2] = mag(add_mul_pos_i(e, p)) * sc;  // |conj(.)| = |.|
+      // the amplitude scale rides on the 1/2 of the split: DC and Nyquist (k = 0) are not doubled
+      const T h = T(0.5) * ((k == 0) ? s_edge : s_mid);
+      const cx<T> e = (z + conj(zp)) * h;
+      const cx<T> p = cmul(z - conj(zp), w) * h;  // i * W * O
+      arow[k] = mag(add_mul_neg_i(e, p));
+      if (k2 != k) arow[k2] = mag(add_mul_pos_i(e, p));  // |conj(.)| = |.|
     }
   });
   __syncthreads();
@@ -1421,7 +1422,7 @@ fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
 // 69.6 KB of LDS (4 workgroups per CU instead of 2, 4-wave instead of 8-wave barriers) and 2.5
 // instead of 5 full-size LDS round trips per frame.
 #ifndef PDSP_SPLIT16K_WAVES
-#define PDSP_SPLIT16K_WAVES 2  // 2 workgroups per CU (177 VGPRs); 3 and 4 spill and measured slower (tools/kbench)
+#define PDSP_SPLIT16K_WAVES 3  // 3 workgroups per CU (153 VGPRs fit the 168 budget; +1 % over 2, tools/kbench)
 #endif
 template <typename T, bool HAS_WIN, bool PEAK>
 __global__ void __launch_bounds__(256, PDSP_SPLIT16K_WAVES)
@@ -1505,12 +1506,14 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
     if constexpr (q == 0) zp = tid == 0 ? z : uhi[0];
     else zp = *(uhi - cpad(TP * q));
     const cx<T> w = mul_w64<T, q>(ws0);                  // W_N^k
-    const cx<T> e = (z + conj(zp)) * T(0.5);
-    const cx<T> p = cmul(z - conj(zp), w) * T(0.5);      // i * W * O, O = (Z - conj Zp)/(2i)
-    const cx<T> xa = add_mul_neg_i(e, p);                // X[k] = E + W*O
-    const cx<T> xb = conj(add_mul_pos_i(e, p));          // X[8192 - k] = conj(E - W*O)
-    const T sc = (k == 0) ? s_edge : s_mid;              // DC and Nyquist are not doubled
-    const T ma = mag(xa) * sc, mb = mag(xb) * sc;
+    // the amplitude scale rides on the 1/2 of the split (DC and Nyquist, k = 0, are not doubled); a
+    // positive scale leaves the phase of the peak untouched
+    const T h = T(0.5) * ((k == 0) ? s_edge : s_mid);
+    const cx<T> e = (z + conj(zp)) * h;
+    const cx<T> p = cmul(z - conj(zp), w) * h;           // i * W * O, O = (Z - conj Zp)/(2i)
+    const cx<T> xa = add_mul_neg_i(e, p);                // scaled X[k] = E + W*O
+    const cx<T> xb = conj(add_mul_pos_i(e, p));          // scaled X[8192 - k] = conj(E - W*O)
+    const T ma = mag(xa), mb = mag(xb);
     if constexpr (PEAK) {
       if (k == 0) {
         dc_amp = ma;
