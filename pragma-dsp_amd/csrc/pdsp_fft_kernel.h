@@ -199,6 +199,24 @@ __device__ __forceinline__ void fft_reg(cx<T> (&a)[R]) {
     a[1] = a[2];
     a[2] = x1;
     return;
+  } else if constexpr (R == 8) {
+    // one radix-2 step (W8^k on the odd half; W8^2 = -i stays pending), then a radix-4 on each half
+    static_for<4>([&](auto kc) {
+      constexpr int k = kc;
+      const cx<T> u = a[k], v = a[k + 4];
+      a[k] = u + v;
+      if constexpr (k == 2) a[k + 4] = u - v;  // times -i inside bfly4_x2_rot
+      else a[k + 4] = mul_w32<T, 4 * k>(u - v);
+    });
+    bfly4(a[0], a[1], a[2], a[3]);            // X[2m] in a[m]
+    bfly4_x2_rot(a[4], a[5], a[6], a[7]);     // X[2m+1] in a[4+m]
+    cx<T> o[8];
+    static_for<8>([&](auto kc) {
+      constexpr int k = kc;
+      o[bitrev(k, 3)] = a[(k & 1) * 4 + (k >> 1)];
+    });
+    static_for<8>([&](auto kc) { a[kc] = o[kc]; });
+    return;
   } else if constexpr (R == 16) {
     // two radix-4 stages: 64 fused adds + 8 twiddle products, no rotation is ever materialised.
     // Stage A over stride 4: y_q of column j lands in a[j + 4q], then times W16^(j*q).
@@ -913,13 +931,14 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       cx<T> w;                                             // W_N^k
       if constexpr (LOG2E == 4) w = mul_w32<T, q>(twk0);   // N = 32*TP: W_N^(TP*q) = W32^q
       else w = (reinterpret_cast<const cx<T> *>(twr) + TP * q)[(unsigned)tid];
-      const cx<T> e = (z + conj(zp)) * T(0.5);             // E
-      const cx<T> p = cmul(z - conj(zp), w) * T(0.5);      // i * O * W, O = (Z - conj Zp)/(2i)
-      const cx<T> xa = add_mul_neg_i(e, p);                // X[k] = E + W*O
-      const cx<T> xb = conj(add_mul_pos_i(e, p));          // X[M-k] = conj(E - W*O)
-      // bins 0 (DC, from k = 0) and M (Nyquist, the partner of k = 0) are not doubled
-      const T sc = (k == 0) ? s_edge : s_mid;
-      const T ma = mag(xa) * sc, mb = mag(xb) * sc;
+      // the amplitude scale rides on the 1/2 of the split; bins 0 (DC, from k = 0) and M (Nyquist, the
+      // partner of k = 0) are not doubled.  A positive scale leaves the phases untouched.
+      const T h = T(0.5) * ((k == 0) ? s_edge : s_mid);
+      const cx<T> e = (z + conj(zp)) * h;                  // scaled E
+      const cx<T> p = cmul(z - conj(zp), w) * h;           // scaled i * O * W, O = (Z - conj Zp)/(2i)
+      const cx<T> xa = add_mul_neg_i(e, p);                // scaled X[k] = E + W*O
+      const cx<T> xb = conj(add_mul_pos_i(e, p));          // scaled X[M-k] = conj(E - W*O)
+      const T ma = mag(xa), mb = mag(xb);
       if constexpr (PEAK) {
         // the mirrored two-sided bins N-k carry identical values at larger indices, so
         // the strict-'>' search never selects them: bins 1..M decide
