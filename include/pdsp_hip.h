@@ -291,6 +291,14 @@ PDSP_API int pdsp_spectrum_host_f64(const double *samples, long long len, double
                                     long long fft_size, int window, int sides,
                                     double *freq_out, double *amp_out, double *phase_out,
                                     pdsp_peak *peak_out, long long *bins_out);
+/* The same on `batch` frames of `len` samples each (contiguous) in ONE call -- the map of the
+ * reference's spectrumStream (src/effect/index.ts:190-194) batched onto the device.  freq_out holds
+ * the one frequency axis (bins values); amp_out / phase_out batch*bins; peak_out batch records.
+ * Row b equals pdsp_spectrum_host_f64 on frame b bit for bit. */
+PDSP_API int pdsp_spectrum_batch_host_f64(const double *frames, long long batch, long long len,
+                                          double sample_rate, long long fft_size, int window, int sides,
+                                          double *freq_out, double *amp_out, double *phase_out,
+                                          pdsp_peak *peak_out, long long *bins_out);
 
 #ifdef __cplusplus
 }

@@ -1026,32 +1026,41 @@ int polar_host_t(const double *re, const double *im, long long n_, double *out, 
   return PDSP_OK;
 }
 
-// The one frame of spectrum() in precision T; plan->mu held by the caller.
+// `batch` frames of spectrum() (each `len` samples, contiguous) in precision T; plan->mu held by the
+// caller.  One frame (the drop-in spectrum()) and many (spectrumBatch) run the same kernel variant per
+// row, so row b of a batch equals the one-frame call on frame b bit for bit.
 template <typename T>
 int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int window, int sides, double *amp_out,
-                    double *phase_out) {
+                    double *phase_out, long long batch = 1) {
   const long long n = plan->n;
   const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
   const long long used = len < n ? len : n;
-  // staging: [frame n][unused n][amp bins][phase bins]
-  if (int rc = ensure_stage(plan, (size_t)(2 * n + 2 * bins) * sizeof(T))) return rc;
+  // staging: [batch frames of n][batch rows of amp][batch rows of phase]; rows start 16-byte aligned
+  const size_t rows = (size_t)batch * (size_t)bins, frames_sz = (size_t)batch * (size_t)n;
+  const size_t amp_off = (frames_sz + 3) & ~(size_t)3, ph_off = (amp_off + rows + 3) & ~(size_t)3;
+  const size_t total = ph_off + rows;
+  if (int rc = ensure_stage(plan, total * sizeof(T))) return rc;
   T *h = (T *)plan->h_stage, *d = (T *)plan->d_stage;
-  for (long long i = 0; i < used; ++i) h[i] = (T)samples[i];
-  for (long long i = used; i < n; ++i) h[i] = T(0);
+  for (long long b = 0; b < batch; ++b) {
+    const double *src = samples + (size_t)b * (size_t)len;
+    T *dst = h + (size_t)b * (size_t)n;
+    for (long long i = 0; i < used; ++i) dst[i] = (T)src[i];
+    for (long long i = used; i < n; ++i) dst[i] = T(0);
+  }
   const T *d_window = nullptr;
   if (n != 1 && window != PDSP_WIN_RECT) {
     if (int rc = plan_window<T>(plan, window, &d_window)) return rc;
   }
   hipStream_t s = plan->stream;
-  T *const z = zero_copy((size_t)(2 * n + 2 * bins) * sizeof(T)) ? stage_device_view<T>(plan) : nullptr;
+  T *const z = zero_copy(total * sizeof(T)) ? stage_device_view<T>(plan) : nullptr;
   if (z) d = z;  // the kernel works on the pinned buffer itself
-  else PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(T), hipMemcpyHostToDevice, s));
-  if (int rc = spectrum_impl<T>(plan, 1, d, n, n, d_window, sides, d + 2 * n, d + 2 * n + bins, nullptr, nullptr, 1.0, s))
+  else PDSP_HIP_TRY(hipMemcpyAsync(d, h, frames_sz * sizeof(T), hipMemcpyHostToDevice, s));
+  if (int rc = spectrum_impl<T>(plan, batch, d, n, n, d_window, sides, d + amp_off, d + ph_off, nullptr, nullptr, 1.0, s))
     return rc;
-  if (!z) PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * n, d + 2 * n, (size_t)(2 * bins) * sizeof(T), hipMemcpyDeviceToHost, s));
+  if (!z) PDSP_HIP_TRY(hipMemcpyAsync(h + amp_off, d + amp_off, (total - amp_off) * sizeof(T), hipMemcpyDeviceToHost, s));
   PDSP_HIP_TRY(hipStreamSynchronize(s));
-  for (long long i = 0; i < bins; ++i) amp_out[i] = (double)h[2 * n + i];
-  for (long long i = 0; i < bins; ++i) phase_out[i] = (double)h[2 * n + bins + i];
+  for (size_t i = 0; i < rows; ++i) amp_out[i] = (double)h[amp_off + i];
+  for (size_t i = 0; i < rows; ++i) phase_out[i] = (double)h[ph_off + i];
   return PDSP_OK;
 }
 
@@ -1369,7 +1378,15 @@ int pdsp_phase_host_f64(const double *re, const double *im, long long n, double 
 int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_rate, long long fft_size, int window,
                            int sides, double *freq_out, double *amp_out, double *phase_out, pdsp_peak *peak_out,
                            long long *bins_out) {
-  if (len < 0 || (len > 0 && !samples)) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+  return pdsp_spectrum_batch_host_f64(samples, 1, len, sample_rate, fft_size, window, sides, freq_out, amp_out, phase_out,
+                                      peak_out, bins_out);
+}
+
+int pdsp_spectrum_batch_host_f64(const double *samples, long long batch, long long len, double sample_rate,
+                                 long long fft_size, int window, int sides, double *freq_out, double *amp_out,
+                                 double *phase_out, pdsp_peak *peak_out, long long *bins_out) {
+  if (batch < 0) return fail(PDSP_ERR_BAD_ARG, "batch must be >= 0, got %lld", batch);
+  if (len < 0 || (len > 0 && batch > 0 && !samples)) return fail(PDSP_ERR_BAD_ARG, "bad samples");
   if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
   // Error order of spectrum.ts:113-132: FFT ctor (power of two) -> createWindow
   // (type; N == 1 returns before the type switch) -> ... -> binFrequencies (rate).
@@ -1386,19 +1403,25 @@ int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_r
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
   const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
-  const bool f64 = host_precision() == 64 && (plan->t64.tw_half || plan->t64.tw);
-  if (int rc = f64 ? spectrum_host_t<double>(plan, samples, len, window, sides, amp_out, phase_out)
-                   : spectrum_host_t<float>(plan, samples, len, window, sides, amp_out, phase_out))
-    return rc;
   if (int rc = pdsp_bin_frequencies(n, sample_rate, sides, freq_out, nullptr)) return rc;
   if (bins_out) *bins_out = bins;
+  if (batch == 0) return PDSP_OK;
+  const bool f64 = host_precision() == 64 && (plan->t64.tw_half || plan->t64.tw);
+  static const double kNoSample = 0.0;  // len == 0: every frame is all zero padding
+  const double *src = len > 0 ? samples : &kNoSample;
+  if (int rc = f64 ? spectrum_host_t<double>(plan, src, len, window, sides, amp_out, phase_out, batch)
+                   : spectrum_host_t<float>(plan, src, len, window, sides, amp_out, phase_out, batch))
+    return rc;
   if (peak_out) {
     // findPeak on the host over the f64 amplitudes: exact strict-'>' and first-wins behaviour
-    const long long pk = pdsp_find_peak_f64(amp_out, bins);
-    peak_out->index = (int32_t)pk;
-    peak_out->frequency = freq_out[pk];
-    peak_out->amplitude = amp_out[pk];
-    peak_out->phase = phase_out[pk];
+    for (long long b = 0; b < batch; ++b) {
+      const double *a = amp_out + (size_t)b * (size_t)bins, *p = phase_out + (size_t)b * (size_t)bins;
+      const long long pk = pdsp_find_peak_f64(a, bins);
+      peak_out[b].index = (int32_t)pk;
+      peak_out[b].frequency = freq_out[pk];
+      peak_out[b].amplitude = a[pk];
+      peak_out[b].phase = p[pk];
+    }
   }
   return PDSP_OK;
 }

@@ -13,6 +13,7 @@
 #include <node_api.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pdsp_hip.h"
@@ -220,6 +221,51 @@ static napi_value Spectrum(napi_env env, napi_callback_info info) {
   return obj;
 }
 
+/* spectrumBatch(frames, batch, frameLen, sampleRate, fftSizeOrMinus1, window, sides, freq, amp, phase, peaks)
+ * frames: batch*frameLen samples; amp/phase: batch*bins; peaks: 4 doubles per frame
+ * (index, frequency, amplitude, phase)   [the map of spectrumStream, src/effect/index.ts:190-194] */
+static napi_value SpectrumBatch(napi_env env, napi_callback_info info) {
+  napi_value argv[11];
+  if (!get_args(env, info, 11, argv)) return NULL;
+  double *x, *freq, *amp, *ph, *pk, rate;
+  size_t nx, nf, na, np, npk;
+  int64_t batch, len, fft_size, window, sides;
+  if (!f64_array(env, argv[0], &x, &nx) || !get_i64(env, argv[1], &batch) || !get_i64(env, argv[2], &len) ||
+      !get_f64(env, argv[3], &rate) || !get_i64(env, argv[4], &fft_size) || !get_i64(env, argv[5], &window) ||
+      !get_i64(env, argv[6], &sides) || !f64_array(env, argv[7], &freq, &nf) || !f64_array(env, argv[8], &amp, &na) ||
+      !f64_array(env, argv[9], &ph, &np) || !f64_array(env, argv[10], &pk, &npk))
+    return NULL;
+  if (batch < 0 || len < 0 || (long long)nx < batch * len) {
+    napi_throw_error(env, NULL, "pdsp_napi: spectrumBatch frames buffer too small");
+    return NULL;
+  }
+  const long long n = fft_size >= 0 ? fft_size : pdsp_next_pow2((long long)len);
+  const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
+  if (pdsp_is_pow2(n) && ((long long)nf < bins || (long long)na < batch * bins || (long long)np < batch * bins ||
+                          (long long)npk < 4 * batch)) {
+    napi_throw_error(env, NULL, "pdsp_napi: spectrumBatch outputs too small");
+    return NULL;
+  }
+  pdsp_peak *recs = (pdsp_peak *)malloc(sizeof(pdsp_peak) * (size_t)(batch > 0 ? batch : 1));
+  if (!recs) {
+    napi_throw_error(env, NULL, "pdsp_napi: out of memory");
+    return NULL;
+  }
+  static double dummy = 0.0;
+  const int rc = pdsp_spectrum_batch_host_f64(nx ? x : &dummy, batch, len, rate, fft_size, (int)window, (int)sides, freq,
+                                              amp, ph, recs, NULL);
+  if (rc == PDSP_OK)
+    for (int64_t b = 0; b < batch; ++b) {
+      pk[4 * b + 0] = (double)recs[b].index;
+      pk[4 * b + 1] = recs[b].frequency;
+      pk[4 * b + 2] = recs[b].amplitude;
+      pk[4 * b + 3] = recs[b].phase;
+    }
+  free(recs);
+  if (rc != PDSP_OK) return throw_pdsp(env);
+  return NULL;
+}
+
 /* binFrequencies(size, sampleRate, sides, out)   [fourier.ts:147-165] */
 static napi_value BinFrequencies(napi_env env, napi_callback_info info) {
   napi_value argv[4];
@@ -271,6 +317,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"planCreate", PlanCreate}, {"transform", Transform},   {"windowMake", WindowMake},
       {"applyWindow", ApplyWindow}, {"magnitude", Magnitude}, {"phase", Phase},
       {"spectrum", Spectrum},     {"binFrequencies", BinFrequencies}, {"fftShift", FftShift},
+      {"spectrumBatch", SpectrumBatch},
       {"nextPow2", NextPow2},     {"deviceCount", DeviceCount},
   };
   for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {

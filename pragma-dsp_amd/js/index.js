@@ -9,6 +9,7 @@ const s = require('./spectrum');
 
 module.exports = {
   spectrum: s.spectrum,
+  spectrumBatch: s.spectrumBatch,  // extension: spectrumStream's map as one device batch
   core: {
     createComplexArray: core.createComplexArray,
     isPowerOfTwo: core.isPowerOfTwo,

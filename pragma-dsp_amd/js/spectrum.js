@@ -34,4 +34,51 @@ function spectrum(samples, options) {
   return { frequencies: frequencies, amplitude: amplitude, phase: phase, peak: peak };
 }
 
-module.exports = { spectrum };
+// spectrumBatch(frames, options): the map of the reference's spectrumStream (src/effect/index.ts:190-194
+// -- one spectrum() result per frame, in order) as ONE device batch per run of equal-length frames
+// instead of one launch + one sync per frame.  Every result equals spectrum(frame, options) exactly;
+// amplitude and phase of a run are views into one buffer each, frequencies is a fresh copy per result.
+function spectrumBatch(frames, options) {
+  const opts = options || {};
+  const sampleRate = opts.sampleRate === undefined || opts.sampleRate === null ? 1 : opts.sampleRate;
+  const sides = opts.sides === undefined || opts.sides === null ? 'one' : opts.sides;
+  const windowType = opts.window === undefined || opts.window === null ? 'rect' : opts.window;
+  const one = sides === 'one';
+  const id = fourier._WINDOW_IDS[windowType];
+  const out = [];
+  let start = 0;
+  while (start < frames.length) {
+    const len = frames[start].length;
+    let end = start + 1;
+    while (end < frames.length && frames[end].length === len) end++;
+    const batch = end - start;
+    const targetSize = opts.fftSize === undefined || opts.fftSize === null ? core.nextPowerOfTwo(len) : opts.fftSize;
+    // error order of spectrum.ts:114-132: FFT ctor, createWindow, binFrequencies
+    if (!core.isPowerOfTwo(targetSize)) throw new Error('FFT size must be power of two, got ' + targetSize);
+    if (targetSize !== 1 && !Object.prototype.hasOwnProperty.call(fourier._WINDOW_IDS, windowType)) {
+      throw new Error('Unsupported window type: ' + windowType);
+    }
+    if (sampleRate <= 0) throw new Error('Sample rate must be positive, got ' + sampleRate);
+    const bins = one ? Math.floor(targetSize / 2) + 1 : targetSize;
+    const flat = new Float64Array(batch * len);
+    for (let b = 0; b < batch; b++) flat.set(core._toF64(frames[start + b]), b * len);
+    const frequencies = new Float64Array(bins);
+    const amplitude = new Float64Array(batch * bins);
+    const phase = new Float64Array(batch * bins);
+    const peaks = new Float64Array(4 * batch);
+    native.spectrumBatch(flat, batch, len, sampleRate, targetSize, id === undefined ? 0 : id, one ? 0 : 1,
+      frequencies, amplitude, phase, peaks);
+    for (let b = 0; b < batch; b++) {
+      out.push({
+        frequencies: b === 0 ? frequencies : frequencies.slice(),
+        amplitude: amplitude.subarray(b * bins, (b + 1) * bins),
+        phase: phase.subarray(b * bins, (b + 1) * bins),
+        peak: { index: peaks[4 * b], frequency: peaks[4 * b + 1], amplitude: peaks[4 * b + 2], phase: peaks[4 * b + 3] },
+      });
+    }
+    start = end;
+  }
+  return out;
+}
+
+module.exports = { spectrum, spectrumBatch };

@@ -63,5 +63,22 @@ for (const n of [1024, 2048, 4096, 16384]) {
   });
   out.cases.push({ n: n, op: 'spectrum(hann, one-sided)', gpu_dropin: sp });
 }
+// spectrumBatch: 256 frames per call
+for (const n of [1024, 4096]) {
+  const frames = [];
+  for (let b = 0; b < 256; b++) {
+    const f = new Float64Array(n);
+    for (let i = 0; i < n; i++) f[i] = rnd();
+    frames.push(f);
+  }
+  const opts = { sampleRate: 48000, fftSize: n, window: 'hann' };
+  for (let w = 0; w < 5; w++) p.spectrumBatch(frames, opts);
+  const reps = 20;
+  const t0 = now();
+  let acc = 0;
+  for (let r = 0; r < reps; r++) acc += p.spectrumBatch(frames, opts)[255].peak.amplitude;
+  const us = (now() - t0) / (reps * 256);
+  out.cases.push({ n: n, op: 'spectrumBatch(256 frames, hann) per frame', gpu_dropin: { median_us: us, min_us: us, p95_us: us }, guard: acc });
+}
 out.checksum_guard = Number.isFinite(seed) ? 1 : 0;
 process.stdout.write(JSON.stringify(out) + '\n');

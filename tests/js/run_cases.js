@@ -36,6 +36,21 @@ const results = cases.map((c) => {
         const r = p.spectrum(c.samples, c.options);
         return { frequencies: arr(r.frequencies), amplitude: arr(r.amplitude), phase: arr(r.phase), peak: r.peak };
       }
+      case 'spectrumBatch': {
+        // every result of the batch call must equal spectrum(frame, options) exactly, in order
+        const rs = p.spectrumBatch(c.frames, c.options);
+        let same = rs.length === c.frames.length;
+        const eq = (a, b) => a.length === b.length && a.every((v, i) => Object.is(v, b[i]) || v === b[i]);
+        for (let i = 0; same && i < rs.length; i++) {
+          const one = p.spectrum(c.frames[i], c.options);
+          same = eq(rs[i].frequencies, one.frequencies) && eq(rs[i].amplitude, one.amplitude) &&
+            eq(rs[i].phase, one.phase) && rs[i].peak.index === one.peak.index &&
+            rs[i].peak.frequency === one.peak.frequency && rs[i].peak.amplitude === one.peak.amplitude &&
+            rs[i].peak.phase === one.peak.phase;
+        }
+        return { same: same, count: rs.length, bins: rs.map((r) => r.amplitude.length),
+                 peak0: rs.length ? rs[0].peak : null, empty: p.spectrumBatch([], c.options).length };
+      }
       case 'createWindow':
         return arr(p.fourier.createWindow(c.type, c.size));
       case 'applyWindow':

@@ -44,7 +44,7 @@ def test_js_exports_and_error_texts(tmp_path):
     cases = [{"op": "exports"}, {"op": "misc"}, {"op": "createWindow", "type": "blackman", "size": 64}]
     cases += [{"op": "throws", "what": w} for w in throws]
     res = run_cases(cases, tmp_path)
-    assert res[0]["root"] == ["spectrum", "core", "fourier"]
+    assert res[0]["root"] == ["spectrum", "spectrumBatch", "core", "fourier"]
     assert res[0]["core"] == ["createComplexArray", "isPowerOfTwo", "nextPowerOfTwo", "Radix2Fft"]
     assert res[0]["fourier"] == ["createWindow", "applyWindow", "FFT", "magnitude", "phase", "fftShift",
                                  "fftShiftComplex", "binFrequencies"]
@@ -84,6 +84,17 @@ def test_js_dropin_parity(tmp_path, oracle_mod, reallife, manifest):
         {"op": "phase", "real": z[0].tolist(), "imag": z[1].tolist()},
         {"op": "throws", "what": "inputLen"},
     ]
+    # spectrumBatch: runs of equal-length frames become one device batch each; results in input order
+    t = np.arange(1024)
+    frames = [(np.sin(2 * np.pi * (8 + i) * t / 1024) + 0.01 * rng.standard_normal(1024)).tolist() for i in range(5)]
+    frames += [rng.standard_normal(300).tolist() for _ in range(3)] + [[0, 1, 0, -1, 0, 1, 0, -1]]
+    batch_cases = [{"op": "spectrumBatch", "frames": frames, "options": {"sampleRate": 48000, "window": "hann"}},
+                   {"op": "spectrumBatch", "frames": frames[:5],
+                    "options": {"sampleRate": 48000, "fftSize": 2048, "sides": "two", "window": "blackman"}}]
+    bres = run_cases(batch_cases, tmp_path)
+    assert bres[0]["same"] is True and bres[0]["count"] == 9 and bres[0]["empty"] == 0
+    assert bres[0]["bins"] == [513] * 5 + [257] * 3 + [5] and bres[0]["peak0"]["index"] == 8
+    assert bres[1]["same"] is True and bres[1]["bins"] == [2048] * 5
     res = run_cases(cases, tmp_path)
     for r in res[:-1]:
         assert "error" not in r or r.get("error") is None, r
