@@ -357,7 +357,90 @@ static int xcd_main(long long batch, int rounds) {
   return 0;
 }
 
+// I/O skeleton of the N=16384 spectrum kernel (argv: frames rounds skel): 64 KB frame in with 16-byte
+// loads, 8193 amplitudes out with dword stores in the kernel's two directions, no transform.
+//   THREADS per frame-workgroup, NT loads / NT stores, HALVES = 1: all loads first; 2: two load/store rounds
+template <int THREADS, bool NT_LD, bool NT_ST, int HALVES, int PITCH = 8193>
+__global__ void __launch_bounds__(THREADS)
+skel_kernel(const float *__restrict__ frames, float *__restrict__ amp, long long nframes) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  constexpr int N = 16384, M = 8192, PER = N / 4 / THREADS;  // V4 loads per thread
+  const int tid = (int)threadIdx.x;
+  const long long row = blockIdx.x;
+  if (row >= nframes) return;
+  const V4 *x4 = reinterpret_cast<const V4 *>(frames + (size_t)row * N);
+  float *arow = amp + (size_t)row * PITCH;
+  #pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+    V4 v[PER / HALVES];
+    #pragma unroll
+    for (int q = 0; q < PER / HALVES; ++q) {
+      const V4 *p = x4 + THREADS * (q + h * (PER / HALVES)) + tid;
+      v[q] = NT_LD ? __builtin_nontemporal_load(p) : *p;
+    }
+    #pragma unroll
+    for (int q = 0; q < PER / HALVES; ++q) {
+      const int k = tid + THREADS * (q + h * (PER / HALVES));  // < 4096
+      const float ma = sqrtf(v[q].x * v[q].x + v[q].y * v[q].y), mb = sqrtf(v[q].z * v[q].z + v[q].w * v[q].w);
+      if (NT_ST) {
+        __builtin_nontemporal_store(ma, arow + k);
+        __builtin_nontemporal_store(mb, arow + (M - k));
+      } else {
+        arow[k] = ma;
+        arow[M - k] = mb;
+      }
+    }
+  }
+  if (tid == 0) arow[4096] = 1.0f;
+}
+
+template <int THREADS, bool NT_LD, bool NT_ST, int HALVES, int PITCH = 8193>
+static void skel_run(const float *x, float *amp, long long frames, int rounds) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> ms;
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((skel_kernel<THREADS, NT_LD, NT_ST, HALVES, PITCH>), dim3(frames), dim3(THREADS), 0, 0, x, amp, frames);
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((skel_kernel<THREADS, NT_LD, NT_ST, HALVES, PITCH>), dim3(frames), dim3(THREADS), 0, 0, x, amp, frames);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    ms.push_back(t / 5);
+  }
+  std::sort(ms.begin(), ms.end());
+  const double bytes = (4.0 * 16384 + 4.0 * 8193) * frames;
+  printf("skel pitch=%d threads=%4d ntld=%d ntst=%d halves=%d  med %.4f ms  %.0f GB/s (max %.0f)\n", PITCH, THREADS, NT_LD, NT_ST, HALVES,
+         ms[ms.size() / 2], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+}
+
+static int skel_main(long long frames, int rounds) {
+  float *x, *amp;
+  CK(hipMalloc(&x, (size_t)frames * 16384 * 4));
+  CK(hipMalloc(&amp, (size_t)frames * 8320 * 4));
+  CK(hipMemset(x, 0, (size_t)frames * 16384 * 4));
+  for (int rep = 0; rep < 2; ++rep) {
+    skel_run<256, true, false, 1>(x, amp, frames, rounds);
+    skel_run<256, true, false, 1, 8208>(x, amp, frames, rounds);  // rows padded to a multiple of 64 B
+    skel_run<256, true, false, 1, 8256>(x, amp, frames, rounds);  // ... of 256 B
+    skel_run<256, true, true, 1, 8256>(x, amp, frames, rounds);
+    skel_run<256, false, false, 1>(x, amp, frames, rounds);
+    skel_run<256, true, true, 1>(x, amp, frames, rounds);
+    skel_run<256, true, false, 2>(x, amp, frames, rounds);
+    skel_run<256, true, false, 4>(x, amp, frames, rounds);
+    skel_run<512, true, false, 1>(x, amp, frames, rounds);
+    skel_run<1024, true, false, 1>(x, amp, frames, rounds);
+    skel_run<128, true, false, 1>(x, amp, frames, rounds);
+    skel_run<128, true, false, 4>(x, amp, frames, rounds);
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 3 && std::string(argv[3]) == "skel") return skel_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "xcd") return xcd_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "mix") return mix_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "c16k") return c16k_main(atoll(argv[1]), atoi(argv[2]));
