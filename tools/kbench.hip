@@ -439,7 +439,74 @@ static int skel_main(long long frames, int rounds) {
   return 0;
 }
 
+// Skeleton of the packed spectrum kernel at mid sizes (argv: MiB rounds skelmid): N-sample frames read
+// with 8-byte loads by TP = N/32 threads each (16 loads per thread), 256/TP frames per workgroup,
+// N/2+1 amplitudes per frame out with dword stores in two directions.
+template <int N>
+__global__ void __launch_bounds__(256) skelmid_kernel(const float *__restrict__ frames, float *__restrict__ amp, long long nframes) {
+  typedef float V2 __attribute__((ext_vector_type(2)));
+  constexpr int M = N / 2, TP = M / 16, ROWS = 256 / TP;
+  const int tid = (int)threadIdx.x % TP, rloc = (int)threadIdx.x / TP;
+  const long long row = (long long)blockIdx.x * ROWS + rloc;
+  if (row >= nframes) return;
+  const V2 *x2 = reinterpret_cast<const V2 *>(frames + (size_t)row * N);
+  float *arow = amp + (size_t)row * (M + 1);
+  V2 v[16];
+  #pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = __builtin_nontemporal_load(x2 + TP * q + tid);
+  #pragma unroll
+  for (int q = 0; q < 9; ++q) {  // bins k and M-k for k = tid + TP*q <= M/2
+    const int k = tid + TP * q;
+    if (q < 8 || tid == 0) {
+      const float ma = sqrtf(v[q % 16].x * v[q % 16].x + v[q % 16].y * v[q % 16].y);
+      const float mb = sqrtf(v[(q + 8) % 16].x * v[(q + 8) % 16].x + v[(q + 8) % 16].y * v[(q + 8) % 16].y);
+      arow[k] = ma;
+      if (M - k != k) arow[M - k] = mb;
+    }
+  }
+}
+
+template <int N>
+static void skelmid_run(const float *x, float *amp, long long mib, int rounds) {
+  const long long frames = mib * 1024 * 1024 / 4 / N;
+  constexpr int ROWS = 256 / (N / 32);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<float> ms;
+  const unsigned blocks = (unsigned)((frames + ROWS - 1) / ROWS);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((skelmid_kernel<N>), dim3(blocks), dim3(256), 0, 0, x, amp, frames);
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((skelmid_kernel<N>), dim3(blocks), dim3(256), 0, 0, x, amp, frames);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    ms.push_back(t / 5);
+  }
+  std::sort(ms.begin(), ms.end());
+  const double bytes = (4.0 * N + 4.0 * (N / 2 + 1)) * frames;
+  printf("skelmid N=%5d  med %.4f ms  %.0f GB/s (max %.0f)\n", N, ms[ms.size() / 2], bytes / ms[ms.size() / 2] / 1e6, bytes / ms[0] / 1e6);
+}
+
+static int skelmid_main(long long mib, int rounds) {
+  float *x, *amp;
+  CK(hipMalloc(&x, (size_t)mib << 20));
+  CK(hipMalloc(&amp, ((size_t)mib << 19) + (1 << 20)));
+  CK(hipMemset(x, 0, (size_t)mib << 20));
+  for (int rep = 0; rep < 2; ++rep) {
+    skelmid_run<1024>(x, amp, mib, rounds);
+    skelmid_run<2048>(x, amp, mib, rounds);
+    skelmid_run<4096>(x, amp, mib, rounds);
+    skelmid_run<8192>(x, amp, mib, rounds);
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 3 && std::string(argv[3]) == "skelmid") return skelmid_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "skel") return skel_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "xcd") return xcd_main(atoll(argv[1]), atoi(argv[2]));
   if (argc > 3 && std::string(argv[3]) == "mix") return mix_main(atoll(argv[1]), atoi(argv[2]));
