@@ -6,10 +6,16 @@
 A "step" is one pass of the hot path over one batch of synthetic input that is
 already resident in HBM: by default BASELINE.json configs[2], the roofline run
 (Radix2Fft.forwardComplex semantics, fp32 planar complex, N=4096, batch=65536
-per GPU).  For N>1 the driver launches one process per GPU (torch.distributed.run);
-the batch is split by rank with no data-path collective (weak scaling: 65,536
-transforms per GPU, configs[4] at N=8), and the timed region is bracketed by a
-barrier + synchronize with the MAX over ranks taken.  Rank 0 prints ONE JSON line.
+per GPU).  For N>1 there is one process per GPU: either the caller starts them
+(torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE) or, when WORLD_SIZE is not
+set, `--gpus N` makes this process the launcher: it starts N child ranks of itself
+(launch_ranks below; the parent never touches the GPU), waits, relays rank 0's JSON line
+and exits non-zero if any child failed.  The batch is split by rank with no data-path
+collective (weak scaling: 65,536 transforms per GPU, configs[4] at N=8 -- the batch idiom
+of bench/reallife/signals.ts:264-270 generalised), and the timed region is bracketed by
+a barrier + synchronize with the MAX over ranks taken.  Rank 0 prints ONE JSON line.
+`--gather` adds the one exchange step of the path, timed on its own: the
+RCCL all-gather of the output slabs and of the 16-byte-per-frame SpectrumPeak records.
 
 Other workloads (parity-checked elsewhere; here for DESIGN.md's numbers):
   --workload spectrum16k   configs[3]: fused Hann+FFT+one-sided amplitude, N=16384,
@@ -223,7 +229,110 @@ def stream_throughput(args, dev) -> int:
     return 0
 
 
-def main() -> int:
+def parity_vs_oracle(kind: str, inputs, outputs, n: int, window: str | None = None):
+    """Outside the timed region: rows of the very buffers the timed steps wrote, checked against the
+    CPU oracle (the checker, never the thing measured).  Stated fp32 tolerance of the path:
+    per row max|got - want| / max|want| <= 1e-5, against the f64 restatement of src/core/fft.ts fed the
+    same f32 inputs.  `kind`: "complex" / "real" (Radix2Fft.forwardComplex / forward rows) or
+    "spectrum" (one-sided amplitude rows of spectrum(), spectrum.ts:116-127)."""
+    import oracle
+    plan = oracle.Plan(n)
+    if kind == "spectrum":
+        x, = inputs
+        got, = outputs
+        want, _, _ = plan.spectrum_batch(x, window=oracle.create_window(window, n) if window else None)
+        err = np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)
+    else:
+        re, im = inputs
+        gre, gim = outputs
+        wre, wim = plan.forward_complex(re, im) if kind == "complex" else plan.forward(re)
+        want = wre + 1j * wim
+        err = np.abs((gre + 1j * gim) - want).max(axis=1) / np.abs(want).max(axis=1)
+    return {"rows": int(err.shape[0]), "max_rel_err": float(err.max()), "tolerance": 1e-5,
+            "ok": bool(err.max() <= 1e-5), "against": "oracle/pdsp_oracle.c (f64), rows drawn with seed 1337"}
+
+
+def read_clocks():
+    """Current sclk / mclk of every amdgpu card sysfs shows (MHz), read once before and once after
+    timing -- context for the box-to-box spread of the same binary, not a measurement."""
+    import glob
+    out = []
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+        rec = {}
+        for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+            try:
+                for line in open(os.path.join(d, fn)):
+                    if line.rstrip().endswith("*"):
+                        rec[key] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+            except Exception:
+                pass
+        if rec:
+            rec["card"] = os.path.basename(os.path.dirname(d))
+            out.append(rec)
+    return out or None
+
+
+def launch_ranks(args, argv) -> int:
+    """`--gpus N` without WORLD_SIZE in the environment: start N child ranks of this script, one per
+    GPU (LOCAL_RANK = rank), wait for them, relay rank 0's JSON line.  This parent never calls into
+    HIP (children are fresh processes, never an exec of an initialised one).  Any child failing makes
+    the others stop and the parent exit non-zero."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.dry_run and not args.share_gpu:
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+        if have < n:
+            print(f"bench.py --gpus {n}: only {have} GPU(s) visible (use --share-gpu for a 1-GPU rehearsal)",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PDSP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + args.launch_timeout
+    rc, out0 = 0, None
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if r == 0:
+                out0 = procs[0].stdout.read()
+            if code != 0:
+                rc = rc or code or 1
+                print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
+        if (rc or time.time() > deadline) and pending:
+            if not rc:
+                print(f"bench.py: ranks {sorted(pending)} still running after {args.launch_timeout} s", file=sys.stderr)
+                rc = 124
+            for r in pending:  # exactly the children started above
+                procs[r].kill()
+            for r in pending:
+                procs[r].wait()
+            if 0 in pending:
+                out0 = procs[0].stdout.read()
+            pending.clear()
+        elif pending:
+            time.sleep(0.05)
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if rc == 0 and not lines:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        print(lines[-1], flush=True)
+    return rc
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -232,19 +341,61 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None, help="spectrum256 only: another frame size (development sweeps)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle baseline + parity rows)")
+    ap.add_argument("--no-also", action="store_true", help="skip the short configs[3] leg attached to the default line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ramp-seconds", type=float, default=0.6, help="untimed clock-ramp before the warm-up steps")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (1-GPU rehearsal)")
+    ap.add_argument("--dist-backend", default=None, help="nccl (= RCCL, default) or gloo (default with --share-gpu / --dry-run)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of the output slabs")
-    args = ap.parse_args()
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of the output slabs and of the peak records")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no compute: launcher + rendezvous + shard + gather + max-over-ranks only (CPU tests)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="testing the launcher: this rank exits with status 3")
+    ap.add_argument("--launch-timeout", type=float, default=900.0)
+    args = ap.parse_args(argv)
+    if args.dist_backend is None:
+        args.dist_backend = "gloo" if (args.share_gpu or args.dry_run) else "nccl"
+    return args
+
+
+def dry_run(args, world: int, rank: int) -> int:
+    """The N>1 plumbing of this file without a GPU: process group, contiguous row split, barrier,
+    max-over-ranks, the gather of (stand-in) 16-byte peak records.  Prints a line that says so; it is
+    not a measurement and carries no value."""
+    import torch.distributed as dist
+    from pragma_dsp_amd.shard import gather_rows, max_over_ranks, my_rows
+    per_gpu = args.batch or 65536
+    row0, row1 = my_rows(per_gpu * world, rank, world)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    rec = torch.arange(row0, row1, dtype=torch.int32).reshape(-1, 1).repeat(1, 4)  # 16 B per row
+    full = gather_rows(rec, per_gpu * world)
+    ok = bool(torch.equal(full[:, 0], torch.arange(per_gpu * world, dtype=torch.int32)))
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    ranks_seen = max_over_ranks(float(rank + 1))
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher / shard / gather plumbing only, no compute)", "value": None,
+                          "unit": "GSample/s", "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
+                          "rows": [row0, row1], "global_batch": per_gpu * world, "gather_ok": ok,
+                          "ranks_seen": int(ranks_seen), "elapsed_s": elapsed, "backend": args.dist_backend}), flush=True)
+    return 0 if ok else 1
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
         local = 0
+    if rank == args.fail_rank:
+        print(f"bench.py: rank {rank} failing on request (--fail-rank)", file=sys.stderr)
+        return 3
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist
@@ -252,6 +403,18 @@ def main() -> int:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.dist_backend)
+    try:
+        if args.dry_run:
+            return dry_run(args, world, rank)
+        return run_rank(args, world, rank, local)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def run_rank(args, world: int, rank: int, local: int) -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the pdsp engine has no CPU fallback)", file=sys.stderr)
         return 2
@@ -281,12 +444,14 @@ def main() -> int:
     assert row1 - row0 == per_gpu
     plan = BatchedFft(n, dev)
     stream = torch.cuda.current_stream(dev)
+    parity_kind, amp = None, None
 
     if args.workload in ("fft4096", "fft16k"):
         re, im = synth_batch(per_gpu, n, dev, seed=1337 + rank)
         ore, oim = torch.empty_like(re), torch.empty_like(im)
         launches_per_step = 1
         bytes_per_launch = 16 * per_gpu * n  # 8 B read + 8 B written per sample
+        parity_kind = "complex"
         kernel_name, kernel_label = "fft_stockham_kernel<float, 12, pdsp::LoadComplex", \
             "fft_stockham_kernel<float, 12, LoadComplex, StoreComplex>"
         if args.workload == "fft16k":
@@ -301,6 +466,7 @@ def main() -> int:
         ore, oim = torch.empty_like(re), torch.empty_like(re)
         launches_per_step = 1
         bytes_per_launch = 12 * per_gpu * n
+        parity_kind = "real"
         kernel_name, kernel_label = "fft_stockham_kernel<float, 12, pdsp::LoadReal", \
             "fft_stockham_kernel<float, 12, LoadReal, StoreComplex>"
 
@@ -328,6 +494,7 @@ def main() -> int:
         amp = torch.empty((chunk, bins), dtype=torch.float32, device=dev)
         launches_per_step = per_gpu // chunk
         bytes_per_launch = (4 * n + 4 * bins) * chunk  # 98,308 B per frame
+        parity_kind = "spectrum"
         kernel_name = kernel_label = "spectrum_split16k_kernel<float, true, false>"
         if args.workload == "spectrum256":
             kernel_name = kernel_label = "spectrum_staged_kernel<float, 7, true>" if n == 256 else f"spectrum kernel of N={n}"
@@ -348,6 +515,7 @@ def main() -> int:
                 dist.barrier()
         torch.cuda.synchronize(dev)
 
+    clocks_before = read_clocks() if rank == 0 else None
     # Untimed clock ramp: a cold MI355X needs ~0.5 s of work before its clocks settle
     # (first 20 launches measured 8 % slower than steady state); then the W warm-up steps.
     t_ramp = time.perf_counter()
@@ -365,16 +533,25 @@ def main() -> int:
         step()
         evs[i + 1].record(stream)  # same stream the kernels are launched on
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     barrier()
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    clocks_after = read_clocks() if rank == 0 else None
 
-    elapsed = max_over_ranks(elapsed, dev)
+    elapsed = max_over_ranks(elapsed_local, dev)
+    launch_ms = float(np.mean(step_ms)) / launches_per_step
+    per_rank_ms = [launch_ms]
+    if world > 1:  # every rank's own kernel time (HIP events on its stream), for the scaling read-out
+        import torch.distributed as dist
+        t = torch.tensor([launch_ms], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        allms = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allms, t)
+        per_rank_ms = [float(x.item()) for x in allms]
 
     # context for the roofline fraction (outside the timed region): the rate at which this box, with
     # these very buffers, copies the input planes to the output planes (torch's device copy kernel)
     copy_gbps = None
-    if args.workload in ("fft4096", "fft16k") and rank == 0:
+    if args.workload in ("fft4096", "fft16k") and rank == 0 and world == 1:
         for _ in range(3):
             ore.copy_(re)
             oim.copy_(im)
@@ -386,29 +563,48 @@ def main() -> int:
         c1.record(stream)
         torch.cuda.synchronize(dev)
         copy_gbps = 10 * bytes_per_launch / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        step()  # the output planes hold the transform again (parity rows are read below)
+        torch.cuda.synchronize(dev)
 
     gather = None
     if args.gather and world > 1 and args.workload in ("fft4096", "real4096"):
-        # the one exchange step of the path: RCCL all-gather of the output slabs,
-        # timed on its own -- at 2 GiB/rank it is xGMI-per-link bound and dwarfs the compute
-        gather_rows(ore, per_gpu * world)  # warm-up (communicator setup)
-        barrier()
-        g0 = time.perf_counter()
-        full_re = gather_rows(ore, per_gpu * world)
-        full_im = gather_rows(oim, per_gpu * world)
+        # The one exchange step of the path, timed on its own.  (i) the full output slabs:
+        # at 2 GiB/rank the all-gather is xGMI-per-link bound and dwarfs the compute.  (ii) the reduced
+        # output a consumer of spectrum() needs -- one 16-byte SpectrumPeak per frame (fused findPeak
+        # over the rows' real plane): ~1 MiB/rank.
+        def timed_gather(tensors, rows_per_rank):
+            gather_rows(tensors[0][:8], 8 * world)  # communicator setup, untimed
+            barrier()
+            g0 = time.perf_counter()
+            outs = [gather_rows(t, rows_per_rank * world) for t in tensors]
+            torch.cuda.synchronize(dev)
+            sec = max_over_ranks(time.perf_counter() - g0, dev)
+            nbytes = sum(t.numel() * t.element_size() for t in tensors)
+            rows = int(outs[0].shape[0])
+            del outs
+            return {"ms": sec * 1e3, "bytes_per_rank": nbytes, "GBps_in_per_gpu": nbytes * (world - 1) / sec / 1e9,
+                    "rows_gathered": rows}
+        pk_i, pk_f, pk_a, pk_p, _, _ = plan.spectrum_peaks(re, "hann", "one", 48000.0)
+        recs = pk_i.new_empty((per_gpu, 4))
+        recs[:, 0] = pk_i
+        recs[:, 1:] = torch.stack([pk_f, pk_a, pk_p], dim=1).view(torch.int32)
         torch.cuda.synchronize(dev)
-        gsec = max_over_ranks(time.perf_counter() - g0, dev)
-        nbytes = (ore.numel() + oim.numel()) * 4
-        gather = {"ms": gsec * 1e3, "bytes_per_rank": nbytes,
-                  "GBps_in_per_gpu": nbytes * (world - 1) / gsec / 1e9,
-                  "rows_gathered": int(full_re.shape[0])}
-        del full_re, full_im
+        if args.dist_backend != "nccl":
+            # gloo rehearsal (1-GPU box): the collective runs on host copies, 4096 rows of the slabs per
+            # rank -- it checks the plumbing; it is not a bandwidth figure
+            gather = {"slabs": timed_gather([ore[:4096].cpu(), oim[:4096].cpu()], 4096),
+                      "peaks_16B_per_frame": timed_gather([recs.cpu()], per_gpu),
+                      "note": "gloo rehearsal on host copies (slabs: 4096 rows per rank)"}
+        else:
+            gather = {"slabs": timed_gather([ore, oim], per_gpu),
+                      "peaks_16B_per_frame": timed_gather([recs], per_gpu)}
+        gather["backend"] = args.dist_backend
 
     if rank == 0:
         samples_per_step = per_gpu * n * world
         value = samples_per_step * args.steps / elapsed / 1e9
-        launch_ms = float(np.mean(step_ms)) / launches_per_step
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        profiled_shape = args.batch is None and args.chunk == 16384
         out = {
             "metric": "batched 1D FFT GSample/s at N=4096 batch=65536; achieved HBM GB/s vs peak"
             if args.workload == "fft4096" else f"GSample/s ({args.workload})",
@@ -434,14 +630,40 @@ def main() -> int:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          # PMC bytes of the committed rocprofv3 passes: only valid for the profiled shape
-                         "traffic": traffic_from_profile(kernel_name) if args.batch is None and args.chunk == 16384 else None,
+                         "traffic": traffic_from_profile(kernel_name) if profiled_shape else None,
+                         "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc pass of this workload, "
+                                           "not measured in this run)" if profiled_shape else None,
                          "kernel": kernel_label,
                          "device_copy_same_buffers_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launch_ms_avg": launch_ms, "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
+            "clocks": {"before": clocks_before, "after": clocks_after, "source": "sysfs pp_dpm_sclk / pp_dpm_mclk"},
         }
+        if world > 1:
+            out["per_rank_kernel_ms"] = per_rank_ms
+            out["compute_phase"] = {"GSample_per_s": value, "samples_per_step": samples_per_step,
+                                    "max_rank_ms_per_step": elapsed / args.steps * 1e3,
+                                    "note": "sum of all ranks' samples / max-over-ranks wall time; no collective inside"}
+            if args.share_gpu:
+                out["rehearsal"] = "all ranks share cuda:0 (1-GPU box): plumbing check, not a scaling point"
         if gather:
             out["gather"] = gather
+        if not args.no_cpu_baseline:
+            # CPU legs, rank 0 only, after the timed region: (i) parity of 256 rows of the timed output
+            # against the oracle, (ii) the oracle timed as the CPU baseline (N = 1 only)
+            g = torch.Generator()
+            g.manual_seed(1337)
+            if parity_kind in ("complex", "real"):
+                sel = torch.randperm(per_gpu, generator=g)[:256].sort().values.to(dev)
+                ins = (re[sel].cpu().numpy(), im[sel].cpu().numpy() if im is not None else None)
+                outs = (ore[sel].cpu().numpy().astype(np.float64), oim[sel].cpu().numpy().astype(np.float64))
+                out["parity"] = parity_vs_oracle(parity_kind, ins, outs, n)
+            elif parity_kind == "spectrum":
+                sel = torch.randperm(re.shape[0], generator=g)[:64 if n > 4096 else 256].sort().values.to(dev)
+                out["parity"] = parity_vs_oracle("spectrum", (re[sel].cpu().numpy(),),
+                                                 (amp[sel].cpu().numpy().astype(np.float64),), n, "hann")
+        if world == 1 and args.workload == "fft4096" and not args.no_also:
+            out["also"] = {"spectrum16k": also_spectrum16k(args, dev, rank)}
         if world == 1 and not args.no_cpu_baseline:
             rows = 2048
             sel = torch.cat([torch.arange(0, rows // 2), torch.arange(per_gpu // 2, per_gpu // 2 + rows // 2)]) \
@@ -450,10 +672,46 @@ def main() -> int:
             him = im[sel.to(dev)].cpu().numpy().astype(np.float64) if im is not None else None
             out["cpu_baseline"] = cpu_baseline(hre, him, n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
     return 0
+
+
+def also_spectrum16k(args, dev, rank: int):
+    """A short leg of BASELINE configs[3] attached to the default line so that the driver-timed record
+    carries it: ONE 16,384-frame chunk (1 GiB of N=16384 real frames, generated on the device) through
+    the fused Hann + FFT + one-sided amplitude kernel, a few steps, HIP events on the launch stream;
+    64 of its rows checked against the oracle.  98,308 algorithmic bytes per frame."""
+    from pragma_dsp_amd.batch import BatchedFft
+    n, chunk, steps = 16384, 16384, 10
+    torch.cuda.empty_cache()
+    plan = BatchedFft(n, dev)
+    x, _ = synth_batch(chunk, n, dev, seed=1337 + rank, complex_noise=False)
+    amp = torch.empty((chunk, n // 2 + 1), dtype=torch.float32, device=dev)
+    plan.window("hann")
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(5):
+        plan.spectrum(x, "hann", "one", out=amp)
+    torch.cuda.synchronize(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record(stream)
+    for i in range(steps):
+        plan.spectrum(x, "hann", "one", out=amp)
+        evs[i + 1].record(stream)
+    torch.cuda.synchronize(dev)
+    ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    nbytes = (4 * n + 4 * (n // 2 + 1)) * chunk
+    avg = float(np.mean(ms))
+    res = {"config": "N=16384 fused hann+FFT+one-sided amplitude, one 16384-frame chunk (configs[3] shape)",
+           "kernel": "spectrum_split16k_kernel<float, true, false>", "steps": steps, "ms": avg, "ms_min": float(np.min(ms)),
+           "GSample_per_s": chunk * n / (avg * 1e-3) / 1e9, "algorithmic_bytes_per_launch": nbytes,
+           "GBps": nbytes / (avg * 1e-3) / 1e9, "frac": nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    if not args.no_cpu_baseline:
+        g = torch.Generator()
+        g.manual_seed(1337)
+        sel = torch.randperm(chunk, generator=g)[:64].sort().values.to(dev)
+        res["parity"] = parity_vs_oracle("spectrum", (x[sel].cpu().numpy(),), (amp[sel].cpu().numpy().astype(np.float64),),
+                                         n, "hann")
+    del x, amp
+    return res
 
 
 if __name__ == "__main__":

@@ -192,7 +192,9 @@ PDSP_API int pdsp_phase_f32(long long count, const float *re, const float *im,
  * out = a OP b for the binary ops, where b holds b_len values and is broadcast over the
  * count/b_len rows of a when b_len < count (b_len must divide count); out = a OP (s_re, s_im)
  * for SCALE (real s_re) and MUL_SCALAR; out = conj(a) for CONJ.  divScalar is MUL_SCALAR by the
- * host-computed reciprocal, as complex.ts:176-186 does.  out may alias a. */
+ * host-computed reciprocal, as complex.ts:176-186 does.  out may alias a, and b may alias out when
+ * b_len == count (every element is read before it is written); a broadcast b (b_len < count) must
+ * not overlap out. */
 typedef enum pdsp_complex_op {
   PDSP_CX_ADD = 0, PDSP_CX_SUB = 1, PDSP_CX_MUL = 2, PDSP_CX_DIV = 3,
   PDSP_CX_CONJ = 4, PDSP_CX_SCALE = 5, PDSP_CX_MUL_SCALAR = 6
@@ -258,6 +260,8 @@ PDSP_API int pdsp_fft_inverse_interleaved_f64(const pdsp_plan *plan, long long b
                                               double *out, pdsp_stream stream);
 PDSP_API int pdsp_apply_window_f64(long long batch, long long n, const double *in,
                                    const double *window, double *out, pdsp_stream stream);
+/* f64 magnitude is hypot(re, im) like the reference's Math.hypot (fourier.ts:106): no overflow /
+ * underflow of the squares at the ends of the double range. */
 PDSP_API int pdsp_magnitude_f64(long long count, const double *re, const double *im,
                                 double *out, pdsp_stream stream);
 PDSP_API int pdsp_phase_f64(long long count, const double *re, const double *im,

@@ -626,30 +626,84 @@ struct Scratch {
 // (spectrum.ts:114-116) -- its dominant one-shot cost; here a repeat call costs no table
 // build, no hipMalloc and no upload.  Leaked on purpose at exit (the HIP runtime may
 // already be gone when static destructors run); pdsp_plan_cache_clear() frees it.
+// Bounded: at most kMaxCachedPlans entries, least recently used evicted first (an entry a call is
+// still running on is pinned and never evicted), so a long-running host that calls spectrum() with
+// ever-changing lengths keeps a bounded set of tables, streams and staging buffers.
+constexpr size_t kMaxCachedPlans = 16;
 struct PlanCache {
+  struct Entry {
+    pdsp_plan *plan = nullptr;
+    unsigned long long last_use = 0;
+    int pins = 0;
+  };
   std::mutex mu;
-  std::map<std::pair<long long, int>, pdsp_plan *> plans;
+  std::map<std::pair<long long, int>, Entry> plans;
+  unsigned long long tick = 0;
 };
 PlanCache &plan_cache() {
   static PlanCache *c = new PlanCache();
   return *c;
 }
 
-int cached_plan(long long n, pdsp_plan **out) {
+// RAII pin of a cached plan for the duration of one host call.
+struct CachedPlan {
+  pdsp_plan *plan = nullptr;
+  std::pair<long long, int> key{0, 0};
+  CachedPlan() = default;
+  CachedPlan(const CachedPlan &) = delete;
+  CachedPlan &operator=(const CachedPlan &) = delete;
+  ~CachedPlan() {
+    if (!plan) return;
+    PlanCache &c = plan_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.plans.find(key);
+    if (it != c.plans.end() && it->second.plan == plan) --it->second.pins;
+  }
+};
+
+int cached_plan(long long n, CachedPlan *out) {
   int dev = 0;
   PDSP_HIP_TRY(hipGetDevice(&dev));
   PlanCache &c = plan_cache();
   std::lock_guard<std::mutex> lk(c.mu);
-  auto it = c.plans.find({n, dev});
-  if (it != c.plans.end()) {
-    *out = it->second;
-    return PDSP_OK;
+  const std::pair<long long, int> key{n, dev};
+  auto it = c.plans.find(key);
+  if (it == c.plans.end()) {
+    // make room first: drop least-recently-used entries nobody is running on
+    while (c.plans.size() >= kMaxCachedPlans) {
+      auto victim = c.plans.end();
+      for (auto jt = c.plans.begin(); jt != c.plans.end(); ++jt)
+        if (jt->second.pins == 0 && (victim == c.plans.end() || jt->second.last_use < victim->second.last_use)) victim = jt;
+      if (victim == c.plans.end()) break;  // every entry is in use: grow past the bound rather than block
+      pdsp_plan_destroy(victim->second.plan);
+      c.plans.erase(victim);
+    }
+    pdsp_plan *p = nullptr;
+    if (int rc = pdsp_plan_create(n, dev, &p)) return rc;
+    it = c.plans.emplace(key, PlanCache::Entry{p, 0, 0}).first;
   }
-  pdsp_plan *p = nullptr;
-  if (int rc = pdsp_plan_create(n, dev, &p)) return rc;
-  c.plans[{n, dev}] = p;
-  *out = p;
+  it->second.last_use = ++c.tick;
+  ++it->second.pins;
+  out->plan = it->second.plan;
+  out->key = key;
   return PDSP_OK;
+}
+
+// Staging above this size is handed back after the call that needed it (a one-off long frame or
+// large batch must not pin host memory and HBM for the life of the plan); smaller staging stays, so
+// repeat calls of ordinary sizes still cost no allocation.  Caller holds plan->mu.
+constexpr size_t kStageKeepBytes = (size_t)64 << 20;
+void trim_stage(pdsp_plan *plan) {
+  if (plan->h_bytes > kStageKeepBytes) {
+    (void)hipHostFree(plan->h_stage);
+    plan->h_stage = nullptr;
+    plan->h_bytes = 0;
+  }
+  if (plan->d_bytes > kStageKeepBytes) {
+    (void)hipFree(plan->d_stage);
+    plan->d_stage = nullptr;
+    plan->d_bytes = 0;
+  }
 }
 
 // Device copy of createWindow(type, N), built once per plan and precision (the window is
@@ -1220,8 +1274,15 @@ int pdsp_plan_create(long long size, int device, pdsp_plan **plan_out) {
 int pdsp_plan_cache_clear(void) {
   PlanCache &c = plan_cache();
   std::lock_guard<std::mutex> lk(c.mu);
-  for (auto &kv : c.plans) pdsp_plan_destroy(kv.second);
-  c.plans.clear();
+  // entries a call is still running on stay (their pin is released by that call)
+  for (auto it = c.plans.begin(); it != c.plans.end();) {
+    if (it->second.pins == 0) {
+      pdsp_plan_destroy(it->second.plan);
+      it = c.plans.erase(it);
+    } else {
+      ++it;
+    }
+  }
   return PDSP_OK;
 }
 
@@ -1344,9 +1405,11 @@ int pdsp_fft_transform_host_f64(pdsp_plan *plan, long long batch, long long in_l
   std::lock_guard<std::mutex> lk(plan->mu);
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
-  if (host_precision() == 64 && plan->t64.tw)
-    return transform_host<double>(plan, batch, re_in, im_in, re_out, im_out, inverse);
-  return transform_host<float>(plan, batch, re_in, im_in, re_out, im_out, inverse);
+  const int rc = (host_precision() == 64 && plan->t64.tw)
+                     ? transform_host<double>(plan, batch, re_in, im_in, re_out, im_out, inverse)
+                     : transform_host<float>(plan, batch, re_in, im_in, re_out, im_out, inverse);
+  trim_stage(plan);
+  return rc;
 }
 
 int pdsp_apply_window_host_f64(const double *in, long long in_len, const double *window, long long window_len,
@@ -1397,8 +1460,9 @@ int pdsp_spectrum_batch_host_f64(const double *samples, long long batch, long lo
   if (sample_rate <= 0) return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
   if (!freq_out || !amp_out || !phase_out) return fail(PDSP_ERR_BAD_ARG, "null output");
   if (int rc = require_device()) return rc;
-  pdsp_plan *plan = nullptr;
-  if (int rc = cached_plan(n, &plan)) return rc;  // plan + window are cached per (size, device)
+  CachedPlan pin;
+  if (int rc = cached_plan(n, &pin)) return rc;  // plan + window are cached per (size, device), LRU-bounded
+  pdsp_plan *const plan = pin.plan;
   std::lock_guard<std::mutex> lk(plan->mu);
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
@@ -1409,9 +1473,10 @@ int pdsp_spectrum_batch_host_f64(const double *samples, long long batch, long lo
   const bool f64 = host_precision() == 64 && (plan->t64.tw_half || plan->t64.tw);
   static const double kNoSample = 0.0;  // len == 0: every frame is all zero padding
   const double *src = len > 0 ? samples : &kNoSample;
-  if (int rc = f64 ? spectrum_host_t<double>(plan, src, len, window, sides, amp_out, phase_out, batch)
-                   : spectrum_host_t<float>(plan, src, len, window, sides, amp_out, phase_out, batch))
-    return rc;
+  const int rc_run = f64 ? spectrum_host_t<double>(plan, src, len, window, sides, amp_out, phase_out, batch)
+                         : spectrum_host_t<float>(plan, src, len, window, sides, amp_out, phase_out, batch);
+  trim_stage(plan);
+  if (rc_run) return rc_run;
   if (peak_out) {
     // findPeak on the host over the f64 amplitudes: exact strict-'>' and first-wins behaviour
     for (long long b = 0; b < batch; ++b) {

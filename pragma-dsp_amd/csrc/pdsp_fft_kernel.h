@@ -309,7 +309,9 @@ __device__ __forceinline__ float mag(const cx<float> z) {
   const cx<float> s = z * z;
   return __builtin_amdgcn_sqrtf(s.x + s.y);
 }
-__device__ __forceinline__ double mag(const cx<double> z) { return sqrt(z.x * z.x + z.y * z.y); }
+// f64 is the drop-in's default arithmetic and the reference's magnitude() is Math.hypot
+// (src/xform/fourier.ts:106): no overflow above 1e154, no underflow below 1e-162.
+__device__ __forceinline__ double mag(const cx<double> z) { return hypot(z.x, z.y); }
 
 // ---- load / store policies ------------------------------------------------
 // ld(row, off, lane) -> cx: fetch point off + lane of row `row` (row < batch).
@@ -1119,7 +1121,9 @@ polar_kernel(const T *__restrict__ re, const T *__restrict__ im, T *__restrict__
   const long long step = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
     const T a = re[i], b = im[i];
-    out[i] = PHASE ? T(atan2(b, a)) : T(sqrt(a * a + b * b));
+    if constexpr (PHASE) out[i] = T(atan2(b, a));
+    else if constexpr (sizeof(T) == 8) out[i] = hypot(a, b);  // Math.hypot, fourier.ts:106 (range-safe)
+    else out[i] = sqrt(a * a + b * b);                        // f32: |x| within ~1e-19 .. 1e19 (header)
   }
 }
 
@@ -1173,10 +1177,12 @@ __device__ __forceinline__ void st_vec(T *p, long long i, const T (&v)[V]) {
   }
 }
 
+// No __restrict__: `out` may alias `a` (the fluent chain works in place) and `b` may be `out` too
+// (chain.mul(chain)); every thread reads its own index of a and b before it writes that index.  A
+// broadcast b (b_len < count) must not overlap `out`.
 template <typename T, int OP, int V>  // V values per thread per step (4 = 16-byte accesses)
 __global__ void __launch_bounds__(256)
-complex_op_kernel(const T *__restrict__ are, const T *__restrict__ aim, const T *__restrict__ bre,
-                  const T *__restrict__ bim, T sre, T sim, T *__restrict__ ore, T *__restrict__ oim,
+complex_op_kernel(const T *are, const T *aim, const T *bre, const T *bim, T sre, T sim, T *ore, T *oim,
                   long long count, long long b_len) {
   constexpr bool kBinary = OP <= kDiv;
   const long long nvec = count / V;

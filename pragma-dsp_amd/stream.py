@@ -54,8 +54,11 @@ class SpectrumStream:
         if not torch.cuda.is_available():
             raise PdspError(_capi.ERR_DEVICE, "no HIP device available (the pdsp engine has no CPU fallback)")
         self.batch_frames = int(batch_frames)
-        # same arithmetic as spectrum(): the host precision (pdsp_set_host_precision), f64 by default
+        # same arithmetic as spectrum(): the host precision (pdsp_set_host_precision), f64 by default;
+        # per size it falls to f32 where the f64 tables do not reach, exactly as
+        # pdsp_spectrum_batch_host_f64 does (_dtype_for)
         self.dtype = torch.float64 if lib.pdsp_set_host_precision(0) == 64 else torch.float32
+        self.slot_bytes = int(opts.get("slotBytes", 1 << 30))  # cap on one slot's pinned input staging
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._plans: dict[int, BatchedFft] = {}     # Map<size, FFT>
         self._freqs: dict[int, np.ndarray] = {}
@@ -76,18 +79,34 @@ class SpectrumStream:
     def _bins(self, n: int) -> int:
         return n // 2 + 1 if self.sides == "one" else n
 
+    def _dtype_for(self, n: int):
+        """f64 only where the f64 device family covers the size (pdsp_max_size(8)); else f32 -- the
+        rule of the one-shot spectrum(), so that every size it accepts streams too."""
+        if self.dtype == torch.float64 and n > int(lib.pdsp_max_size(8)):
+            return torch.float32
+        return self.dtype
+
+    def _frames_per_slot(self, n: int) -> int:
+        """batch_frames, clamped so that one slot's pinned input buffer stays under slot_bytes (a slot of
+        1024 frames of 2^20 f64 points would pin 8 GiB); at least one frame."""
+        per_frame = n * (8 if self._dtype_for(n) == torch.float64 else 4)
+        return max(1, min(self.batch_frames, self.slot_bytes // max(per_frame, 1)))
+
     def _free_slot(self, n: int) -> tuple[_Slot, list]:
-        ready = []
+        """A staging slot of size n that is neither being filled nor in flight.  When both slots of
+        that size are busy the oldest pending batches are harvested -- whatever their size: results
+        leave in input order -- until one of them comes free; every harvested result is returned."""
+        ready: list = []
         slots = self._slots.setdefault(n, [])
-        for s in slots:
-            if not s.in_flight and s.count == 0:
+        while True:
+            for s in slots:
+                if not s.in_flight and s.count == 0:
+                    return s, ready
+            if len(slots) < 2:
+                s = _Slot(self._frames_per_slot(n), n, self._bins(n), self.device, self._dtype_for(n))
+                slots.append(s)
                 return s, ready
-        if len(slots) < 2:
-            s = _Slot(self.batch_frames, n, self._bins(n), self.device, self.dtype)
-            slots.append(s)
-            return s, ready
-        ready = self._harvest_oldest()  # both busy: wait for the older one
-        return self._free_slot(n)[0], ready
+            ready += self._harvest_oldest()  # both busy: wait for the oldest batch in flight
 
     def _submit(self) -> None:
         n, s = self._n, self._fill
@@ -95,7 +114,7 @@ class SpectrumStream:
             return
         plan = self._plans.get(n)
         if plan is None:
-            plan = self._plans[n] = BatchedFft(n, self.device, dtype=self.dtype)
+            plan = self._plans[n] = BatchedFft(n, self.device, dtype=self._dtype_for(n))
         win = None if (self.window == "rect" or n == 1) else plan.window(self.window)
         cnt, bins = s.count, self._bins(n)
         with torch.cuda.stream(self._copy):
@@ -149,7 +168,7 @@ class SpectrumStream:
         row[:used] = x[:used]
         row[used:] = 0.0
         s.count += 1
-        if s.count == self.batch_frames:
+        if s.count == s.h_in.shape[0]:  # the slot is full (batch_frames, or fewer under the byte budget)
             self._submit()
             # keep one batch in flight: harvest everything older than the newest submission
             while len(self._pending) > 1:

@@ -51,6 +51,10 @@ const results = cases.map((c) => {
         return { same: same, count: rs.length, bins: rs.map((r) => r.amplitude.length),
                  peak0: rs.length ? rs[0].peak : null, empty: p.spectrumBatch([], c.options).length };
       }
+      case 'spectrumBatchFull':
+        // every result in full, for a direct comparison with the CPU oracle on the Python side
+        return p.spectrumBatch(c.frames, c.options).map((r) => ({
+          frequencies: arr(r.frequencies), amplitude: arr(r.amplitude), phase: arr(r.phase), peak: r.peak }));
       case 'createWindow':
         return arr(p.fourier.createWindow(c.type, c.size));
       case 'applyWindow':

@@ -91,10 +91,31 @@ def test_js_dropin_parity(tmp_path, oracle_mod, reallife, manifest):
     batch_cases = [{"op": "spectrumBatch", "frames": frames, "options": {"sampleRate": 48000, "window": "hann"}},
                    {"op": "spectrumBatch", "frames": frames[:5],
                     "options": {"sampleRate": 48000, "fftSize": 2048, "sides": "two", "window": "blackman"}}]
+    batch_cases += [dict(c, op="spectrumBatchFull") for c in batch_cases]
     bres = run_cases(batch_cases, tmp_path)
     assert bres[0]["same"] is True and bres[0]["count"] == 9 and bres[0]["empty"] == 0
     assert bres[0]["bins"] == [513] * 5 + [257] * 3 + [5] and bres[0]["peak0"]["index"] == 8
     assert bres[1]["same"] is True and bres[1]["bins"] == [2048] * 5
+    # ... and every streamed result against the ORACLE's spectrum() directly (the map of
+    # spectrumStream, src/effect/index.ts:143-194, test/reallife/effect.test.ts:34-45): default f64 mode
+    for c, full in zip(batch_cases[:2], bres[2:]):
+        opts = c["options"]
+        assert len(full) == len(c["frames"])
+        for frame, g in zip(c["frames"], full):
+            w = oracle_mod.spectrum(frame, sample_rate=opts["sampleRate"], fft_size=opts.get("fftSize"),
+                                    window=opts.get("window", "rect"), sides=opts.get("sides", "one"))
+            top = max(w["amplitude"].max(), 1e-300)
+            assert np.array_equal(g["frequencies"], w["frequencies"])
+            assert np.abs(np.array(g["amplitude"]) - w["amplitude"]).max() <= 1e-12 * top
+            mask = w["amplitude"] > 1e-4 * top
+            dph = (np.array(g["phase"]) - w["phase"] + np.pi) % (2 * np.pi) - np.pi
+            assert np.abs(dph[mask]).max(initial=0) <= 1e-9
+            n = len(w["amplitude"])
+            if opts.get("sides", "one") == "one":
+                assert g["peak"]["index"] == w["peak"]["index"]
+            else:
+                assert g["peak"]["index"] in (w["peak"]["index"], (n - w["peak"]["index"]) % n)
+            assert abs(g["peak"]["amplitude"] - w["peak"]["amplitude"]) <= 1e-12 * top
     res = run_cases(cases, tmp_path)
     for r in res[:-1]:
         assert "error" not in r or r.get("error") is None, r

@@ -258,3 +258,19 @@ def test_node_oracle_matches_goldens_and_c_oracle(oracle_mod, reallife, v01, man
         assert max(np.abs(fre - wre).max(), np.abs(fim - wim).max()) < 1e-12 * n
         wre, wim = plan.inverse(z[0], z[1])
         assert max(np.abs(bre - wre).max(), np.abs(bim - wim).max()) < 1e-14
+
+
+def test_oracle_spectrum_peak_vs_golden_peak_metadata(oracle_mod, reallife, manifest):
+    """findPeak + one-sided scaling of the oracle against the peak metadata the reference's generator
+    stored for all 35 cases (peakBin / peakMagnitude / peakPhase, scripts/gen_reallife_refs.py:149-153,
+    :503-517), as the reference's tests use them (scaling.test.ts:27-31, :150-201; phase.test.ts:92-97).
+    The expectation helper is the one the GPU test uses (tests/test_gpu_golden_peaks.py)."""
+    from test_gpu_golden_peaks import FS, N, expected, wrap
+    for c in manifest["reallife"]:
+        k, amp, ph, _ = expected(c, reallife)
+        w = oracle_mod.spectrum(reallife[c["name"] + "/signal"], sample_rate=FS, fft_size=N)
+        assert w["peak"]["index"] == k, c["name"]
+        assert abs(w["peak"]["amplitude"] - amp) <= 1e-10 * max(1.0, amp), c["name"]
+        assert w["peak"]["frequency"] == k * FS / N
+        if float(c["peakMagnitude"]) > 1e-6:
+            assert wrap(w["peak"]["phase"] - ph) < 1e-10, c["name"]
