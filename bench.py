@@ -252,13 +252,23 @@ def parity_vs_oracle(kind: str, inputs, outputs, n: int, window: str | None = No
             "ok": bool(err.max() <= 1e-5), "against": "oracle/pdsp_oracle.c (f64), rows drawn with seed 1337"}
 
 
-def read_clocks():
+def read_clocks(dev=None):
     """Current sclk / mclk of every amdgpu card sysfs shows (MHz), read once before and once after
-    timing -- context for the box-to-box spread of the same binary, not a measurement."""
+    timing -- context for the box-to-box spread of the same binary, not a measurement.
+    The host's other cards are listed too (they belong to other users); `"ours": true` marks the card
+    whose PCI address is the device this rank runs on."""
     import glob
+    mine = None
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        mine = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except Exception:
+        pass
     out = []
     for d in sorted(glob.glob("/sys/class/drm/card*/device")):
         rec = {}
+        if mine and mine in os.path.realpath(d):
+            rec["ours"] = True
         for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
             try:
                 for line in open(os.path.join(d, fn)):
@@ -515,7 +525,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                 dist.barrier()
         torch.cuda.synchronize(dev)
 
-    clocks_before = read_clocks() if rank == 0 else None
+    clocks_before = read_clocks(dev) if rank == 0 else None
     # Untimed clock ramp: a cold MI355X needs ~0.5 s of work before its clocks settle
     # (first 20 launches measured 8 % slower than steady state); then the W warm-up steps.
     t_ramp = time.perf_counter()
@@ -536,7 +546,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     elapsed_local = time.perf_counter() - t0
     barrier()
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
-    clocks_after = read_clocks() if rank == 0 else None
+    clocks_after = read_clocks(dev) if rank == 0 else None
 
     elapsed = max_over_ranks(elapsed_local, dev)
     launch_ms = float(np.mean(step_ms)) / launches_per_step
@@ -681,16 +691,18 @@ def also_spectrum16k(args, dev, rank: int):
     the fused Hann + FFT + one-sided amplitude kernel, a few steps, HIP events on the launch stream;
     64 of its rows checked against the oracle.  98,308 algorithmic bytes per frame."""
     from pragma_dsp_amd.batch import BatchedFft
-    n, chunk, steps = 16384, 16384, 10
+    n, chunk, steps = 16384, 16384, 20
     torch.cuda.empty_cache()
     plan = BatchedFft(n, dev)
     x, _ = synth_batch(chunk, n, dev, seed=1337 + rank, complex_noise=False)
     amp = torch.empty((chunk, n // 2 + 1), dtype=torch.float32, device=dev)
     plan.window("hann")
     stream = torch.cuda.current_stream(dev)
-    for _ in range(5):
-        plan.spectrum(x, "hann", "one", out=amp)
-    torch.cuda.synchronize(dev)
+    t_ramp = time.perf_counter()  # the clocks fell back during the host-side parity leg: ramp again, untimed
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        for _ in range(10):
+            plan.spectrum(x, "hann", "one", out=amp)
+        torch.cuda.synchronize(dev)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     evs[0].record(stream)
     for i in range(steps):
