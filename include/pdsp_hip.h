@@ -95,17 +95,22 @@ PDSP_API int pdsp_device_count(void);
 PDSP_API int pdsp_max_size(int scalar_bytes);
 
 /* Kernel selection switch for A/B tests (process-wide; returns the previous value): 1 (default)
- * runs whole aligned one-sided N = 16384 f32 spectra on spectrum_split16k_kernel (two 4096-point
- * sub-transforms per workgroup) and 16-byte aligned N = 16384 f32 complex/real rows on
- * fft_split4_kernel (four 4096-point sub-transforms per workgroup), and N = 8192 rows (f64; f32
- * real input) on fft_split2_kernel; 0 on spectrum_packed_kernel<13> and the single-pass
- * fft_stockham_kernel.  Same results within rounding.  (Bit 1 set also routes f32 complex
+ * runs whole pair-aligned one-sided N = 16384 f32 spectra on spectrum_dif16k_kernel (two 4096-point
+ * sub-transforms per workgroup, decimation in frequency on top) and 16-byte aligned N = 16384 f32
+ * complex/real rows on fft_split4_kernel (four 4096-point sub-transforms per workgroup), and N = 8192
+ * rows (f64; f32 real input) on fft_split2_kernel; 0 on spectrum_packed_kernel<13> and the
+ * single-pass fft_stockham_kernel.  Same results within rounding.  (Bit 1 set also routes f32 complex
  * N = 8192 rows to fft_split2_kernel: a development A/B switch.) */
 PDSP_API int pdsp_set_split16k(int enabled);
 /* Same kind of switch for 32 <= N <= 256 transforms on 16-byte aligned planes: 1 (default) =
  * fft_staged_kernel (the workgroup's contiguous 4096-point chunk staged through LDS with coalesced
  * 16-byte accesses), 0 = the direct kernel. */
 PDSP_API int pdsp_set_staged_small(int enabled);
+/* 1 (default): a window argument that IS one of the plan's own tables (pdsp_plan_window_f32) is
+ * evaluated inside the N = 16384 f32 spectrum kernel (createWindow fused, see below); 0: it is read
+ * as a table like any caller-supplied window.  A/B switch for the parity tests; returns the
+ * previous value. */
+PDSP_API int pdsp_set_fused_window(int enabled);
 
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).
  *   64 (default): f64 on the device for every size up to 2^26 -- the drop-in then meets the
@@ -148,6 +153,17 @@ PDSP_API long long pdsp_plan_size(const pdsp_plan *plan);
  * spectrum() rebuilds plan and window on every call, spectrum.ts:114-116).  This frees it. */
 PDSP_API int pdsp_plan_cache_clear(void);
 PDSP_API int pdsp_plan_device(const pdsp_plan *plan);
+
+/* The plan's own device copy of createWindow(type, N) (src/xform/fourier.ts:14-52; built in f64 on
+ * the host, rounded once, uploaded on first use, owned by the plan and valid for its lifetime) -- the
+ * Map<"type:size", window> of FourierLive (src/effect/index.ts:39-48) per plan.  Passing this pointer
+ * as `window` to pdsp_spectrum_f32 / pdsp_spectrum_peaks_f32 tells the engine WHICH window it is: for
+ * N = 16384 f32 frames the cosine-sum window a0 - a1 cos(2 pi n/(N-1)) + a2 cos(4 pi n/(N-1)) is then
+ * evaluated in registers (createWindow + applyWindow fused into the frame load; values agree with
+ * the table to ~2e-7 absolute) instead of being re-read, 64 KB per frame, from L2.  Any other
+ * pointer is used as a table of N values. */
+PDSP_API int pdsp_plan_window_f32(pdsp_plan *plan, int type, const float **window_out);
+PDSP_API int pdsp_plan_window_f64(pdsp_plan *plan, int type, const double **window_out);
 
 /* ---- device-pointer batched transforms (f32) --------------------------- */
 

@@ -70,6 +70,9 @@ def _load() -> C.CDLL:
         "pdsp_set_host_precision": ([i32], i32),
         "pdsp_set_split16k": ([i32], i32),
         "pdsp_set_staged_small": ([i32], i32),
+        "pdsp_set_fused_window": ([i32], i32),
+        "pdsp_plan_window_f32": ([vp, i32, C.POINTER(vp)], i32),
+        "pdsp_plan_window_f64": ([vp, i32, C.POINTER(vp)], i32),
         "pdsp_is_pow2": ([ll], i32),
         "pdsp_next_pow2": ([ll], ll),
         "pdsp_window_make": ([i32, ll, dp], i32),

@@ -27,6 +27,28 @@ def _ptr(t) -> C.c_void_p:
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class PlanWindow:
+    """The plan's own device copy of createWindow(kind, N) (pdsp_plan_window_*): a borrowed device
+    pointer, valid while the plan lives.  Passing it as `window` tells the engine which window it is,
+    so the kernels that can fuse createWindow do (include/pdsp_hip.h); `.tensor()` gives a torch copy."""
+
+    def __init__(self, plan: "BatchedFft", kind: str):
+        out = C.c_void_p()
+        check(getattr(lib, "pdsp_plan_window_" + plan._sfx)(plan._h, _capi.WINDOW_TYPES[kind], C.byref(out)))
+        self._plan = plan  # keeps the owner alive
+        self._p = out.value
+        self.kind = kind
+        self.shape = (plan.size,)
+        self.dtype = plan.dtype
+        self.device = plan.device
+
+    def data_ptr(self) -> int:
+        return self._p
+
+    def tensor(self) -> torch.Tensor:
+        return torch.from_numpy(createWindow(self.kind, self.shape[0])).to(self.dtype).to(self.device)
+
+
 class BatchedFft:
     """One plan, many rows.  Tensors are contiguous, shape [..., N], on the plan's GPU, of the
     plan's dtype: torch.float32 (default; every size up to 16384) or torch.float64 (complex
@@ -77,13 +99,15 @@ class BatchedFft:
             return ore, oim
         return torch.empty_like(like), torch.empty_like(like)
 
-    def window(self, kind: str) -> torch.Tensor:
-        """Device copy (f32) of createWindow(kind, N); cached per kind like
-        FourierLive's window cache (src/effect/index.ts:39-48)."""
+    def window(self, kind: str) -> PlanWindow:
+        """The plan's device copy of createWindow(kind, N), cached per kind like FourierLive's window
+        cache (src/effect/index.ts:39-48).  A window named by kind is known to the engine (fused
+        createWindow where a kernel supports it); a caller's own tensor is read as a table."""
         w = self._windows.get(kind)
         if w is None:
-            w = torch.from_numpy(createWindow(kind, self.size)).to(self.dtype).to(self.device)
-            self._windows[kind] = w
+            if kind not in _capi.WINDOW_TYPES:
+                raise PdspError(_capi.ERR_WINDOW_TYPE, f"Unsupported window type: {kind}")
+            w = self._windows[kind] = PlanWindow(self, kind)
         return w
 
     # -- transforms ------------------------------------------------------------
@@ -148,7 +172,8 @@ class BatchedFft:
             if win is not None:
                 if win.shape[-1] != self.size:
                     raise PdspError(_capi.ERR_WINDOW_LENGTH, "Window length must match input length.")
-                self._check(win, "window")
+                if not isinstance(win, PlanWindow):
+                    self._check(win, "window")
         shape = tuple(frames.shape[:-1])
         amp = out if out is not None else torch.empty(shape + (bins,), dtype=self.dtype, device=self.device)
         ph = torch.empty(shape + (bins,), dtype=self.dtype, device=self.device) if want_phase else None

@@ -26,6 +26,7 @@ thread_local std::string g_err;
 // development switches (tools / tests): 0 routes N = 16384 spectra to spectrum_packed_kernel<13>,
 // and 32 <= N <= 256 transforms to the direct kernel instead of fft_staged_kernel
 int g_split16k = 1;
+int g_fused_window = 1;  // pdsp_set_fused_window: plan-owned cosine-sum windows evaluated in the kernel
 int g_split8k_f32 = 0;  // f32 N = 8192 rows on fft_split2_kernel too (A/B: pdsp_set_split16k bit 1)
 int g_staged_small = 1;
 
@@ -96,6 +97,10 @@ struct Tables {
   T2 *tws4 = nullptr;  // rows of 16384 points (log2n2 == 14): W_16384^k, k < 768 (fft_split4_kernel)
   T2 *tws2 = nullptr;  // rows of 8192 points (log2n2 == 13): W_8192^k, k < 256 (fft_split2_kernel; uses tw12 too)
   T *win[4] = {nullptr, nullptr, nullptr, nullptr};  // createWindow(type, N), built on first use
+  // N = 16384, f32: per-thread bases and per-q constants of the fused cosine-sum windows
+  // (spectrum_dif16k_kernel, WinFused): cos / sin of f*(2 tid + e) and of f*512 q (+ 8192), f = 2 pi / (N - 1)
+  float *wf_base = nullptr;
+  float *wf_step = nullptr;
   // four-step path (N beyond the single-pass limit): `tw` then belongs to the N2-point rows,
   // N1 = N / N2, and W_N^m = twa[m >> 9] * twb[m & 511]
   int log2n2 = 0;  // log2 of the transform `tw` serves (== log2 N when single-pass)
@@ -106,6 +111,9 @@ struct Tables {
   void release() {
     if (tw12) (void)hipFree(tw12);
     tw12 = nullptr;
+    if (wf_base) (void)hipFree(wf_base);
+    if (wf_step) (void)hipFree(wf_step);
+    wf_base = wf_step = nullptr;
     if (tws4) (void)hipFree(tws4);
     tws4 = nullptr;
     if (tws2) (void)hipFree(tws2);
@@ -816,6 +824,26 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
       e = hipMalloc((void **)&t.tw12, t12.size() * sizeof(T2));
       if (e == hipSuccess) e = hipMemcpy(t.tw12, t12.data(), t12.size() * sizeof(T2), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && log2n == 14 && sizeof(T) == 4) {
+      // fused createWindow (fourier.ts:14-52: f = 2 pi i / (size - 1)): angle-addition tables, built in f64
+      const double f = 2.0 * M_PI / (double)(size - 1);
+      std::vector<float> base(256 * 4), step(64);
+      for (int tdx = 0; tdx < 256; ++tdx)
+        for (int ee = 0; ee < 2; ++ee) {
+          base[4 * tdx + 2 * ee] = (float)std::cos(f * (2 * tdx + ee));
+          base[4 * tdx + 2 * ee + 1] = (float)std::sin(f * (2 * tdx + ee));
+        }
+      for (int q = 0; q < 16; ++q) {
+        step[2 * q] = (float)std::cos(f * 512 * q);
+        step[2 * q + 1] = (float)std::sin(f * 512 * q);
+        step[32 + 2 * q] = (float)std::cos(f * (512 * q + 8192));
+        step[32 + 2 * q + 1] = (float)std::sin(f * (512 * q + 8192));
+      }
+      e = hipMalloc((void **)&t.wf_base, base.size() * sizeof(float));
+      if (e == hipSuccess) e = hipMemcpy(t.wf_base, base.data(), base.size() * sizeof(float), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc((void **)&t.wf_step, step.size() * sizeof(float));
+      if (e == hipSuccess) e = hipMemcpy(t.wf_step, step.data(), step.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
   }
   return e;
 }
@@ -938,18 +966,39 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     }
     bool launched = false;
     if constexpr (sizeof(T) == 4) {
-      // N = 16384: two 4096-point sub-transforms per 256-thread workgroup (4 frames per CU instead of 2)
-      if (fast && plan->log2n == 14 && g_split16k && ((uintptr_t)frames & 15) == 0 && (frame_stride & 3) == 0 &&
-          (window == nullptr || ((uintptr_t)window & 15) == 0)) {
+      // N = 16384: two 4096-point sub-transforms per 256-thread workgroup (3 frames per CU instead of 2),
+      // decimation in frequency on top (spectrum_dif16k_kernel).  A window that is one of the PLAN'S OWN
+      // tables (pdsp_plan_window_f32) is known by kind, and createWindow is fused into the kernel: the
+      // reference's windows are cosine sums (fourier.ts:14-52), evaluated in registers instead of being
+      // read back, 64 KB per frame, from L2.  Any other window pointer is read as a table.
+      if (fast && plan->log2n == 14 && g_split16k && t.wf_base) {
         pdsp::PeakRec *pk = reinterpret_cast<pdsp::PeakRec *>(peaks_out);
-#define PDSP_SPLIT(W, P)                                                                                         \
-  hipLaunchKernelGGL((pdsp::spectrum_split16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames, \
-                     window, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch)
-        if (window && pk) PDSP_SPLIT(true, true);
-        else if (window) PDSP_SPLIT(true, false);
-        else if (pk) PDSP_SPLIT(false, true);
-        else PDSP_SPLIT(false, false);
-#undef PDSP_SPLIT
+        int kind = -1;  // -1: caller's table
+        for (int k = 0; k < 4; ++k)
+          if (window && window == t.win[k]) kind = k;
+        pdsp::WinFused wf{t.wf_base, t.wf_step, 0.f, 0.f, 0.f};
+        int mode = window ? 1 : 0;
+        if (kind == PDSP_WIN_RECT) mode = 0;  // createWindow("rect") is all ones
+        else if (kind == PDSP_WIN_HANN) mode = 2, wf.k0 = 0.5f, wf.k1 = -0.5f;
+        else if (kind == PDSP_WIN_HAMMING) mode = 2, wf.k0 = 0.54f, wf.k1 = -0.46f;
+        else if (kind == PDSP_WIN_BLACKMAN) mode = 3, wf.k0 = 0.42f - 0.08f, wf.k1 = -0.5f, wf.k2 = 2 * 0.08f;
+        if (!g_fused_window && mode >= 2) mode = 1;
+#define PDSP_DIF(W, P)                                                                                              \
+  hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames,  \
+                     window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch)
+#define PDSP_DIF_P(W)    \
+  do {                   \
+    if (pk) PDSP_DIF(W, true); \
+    else PDSP_DIF(W, false);   \
+  } while (0)
+        switch (mode) {
+          case 0: PDSP_DIF_P(0); break;
+          case 1: PDSP_DIF_P(1); break;
+          case 2: PDSP_DIF_P(2); break;
+          default: PDSP_DIF_P(3); break;
+        }
+#undef PDSP_DIF_P
+#undef PDSP_DIF
         PDSP_HIP_TRY(hipGetLastError());
         launched = true;  // a requested peak-index array is filled by the common tail below
       }
@@ -1147,6 +1196,27 @@ int pdsp_set_split16k(int enabled) {
   g_split8k_f32 = (enabled & 2) ? 1 : 0;
   return prev;
 }
+
+int pdsp_set_fused_window(int enabled) {
+  const int prev = g_fused_window;
+  g_fused_window = enabled ? 1 : 0;
+  return prev;
+}
+
+#define PDSP_DEFINE_PLAN_WINDOW(SUFFIX, T)                                                                  \
+  int pdsp_plan_window_##SUFFIX(pdsp_plan *plan, int type, const T **window_out) {                          \
+    if (!plan || !window_out) return fail(PDSP_ERR_BAD_ARG, "null plan or output");                        \
+    *window_out = nullptr;                                                                                 \
+    if (type < PDSP_WIN_RECT || type > PDSP_WIN_BLACKMAN)                                                  \
+      return fail(PDSP_ERR_WINDOW_TYPE, "Unsupported window type: %d", type);                              \
+    std::lock_guard<std::mutex> lk(plan->mu);                                                              \
+    DeviceGuard g(plan->device);                                                                           \
+    PDSP_HIP_TRY(g.err);                                                                                   \
+    return plan_window<T>(plan, type, window_out);                                                         \
+  }
+PDSP_DEFINE_PLAN_WINDOW(f32, float)
+PDSP_DEFINE_PLAN_WINDOW(f64, double)
+#undef PDSP_DEFINE_PLAN_WINDOW
 
 int pdsp_set_staged_small(int enabled) {
   const int prev = g_staged_small;

@@ -85,7 +85,9 @@ constexpr int bitrev(int x, int bits) {
   return y;
 }
 
-#ifdef PDSP_STAMPS
+// Empty asm that claims to modify every element: the values become opaque at this point (keeps loads
+// from sinking past it in the stamped build; keeps loop-invariant values from being hoisted with
+// everything derived from them in the multi-frame kernels).
 template <typename T, int E, int I = 0>
 __device__ __forceinline__ void pin_regs(T __attribute__((ext_vector_type(2))) (&a)[E]) {
   if constexpr (I < E) {
@@ -93,7 +95,6 @@ __device__ __forceinline__ void pin_regs(T __attribute__((ext_vector_type(2))) (
     pin_regs<T, E, I + 1>(a);
   }
 }
-#endif
 
 // ---- complex helpers on cx ---------------------------------------------------
 
@@ -282,6 +283,17 @@ __device__ __forceinline__ long long uniform_row(long long row) {
   if constexpr (TP >= 64) return (long long)__builtin_amdgcn_readfirstlane((int)row);
   else return row;
 }
+
+// Order of a kernel's first loads: 1 = the L2-resident tables a thread needs (twiddle bases, split
+// twiddles, window values) are requested BEFORE its streamed row (HBM).  The memory counter retires in
+// issue order and the vector-memory pipeline is a queue: table loads issued behind the row loads sit
+// behind 16-64 KB of streaming requests and their data is not usable until every older HBM load is back.
+// Round 1 issued them "right behind the row loads"; measured on the N=16384 spectrum kernel
+// 5.07-5.12 -> 5.40 TB/s (tools/kbench spec).  0 restores the round-1 order for A/B runs.
+#ifndef PDSP_TABLES_FIRST
+#define PDSP_TABLES_FIRST 1
+#endif
+__device__ __forceinline__ void load_order_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // Streamed rows are touched exactly once: non-temporal loads/stores keep them from
 // displacing the twiddle/window tables in L2 (+4..10 % on the row-pattern copy and on
@@ -653,15 +665,19 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
   cx<T> *const lrow = lds + (NP > 1 ? rloc * TR::LROW : 0);
 
   cx<T> x[E];
-  static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
 #ifndef PDSP_C2C_TABLE_TWIDDLES
-  constexpr bool kRegTw = (TP >= 16 && NP > 1);  // twiddle bases in registers, fetched behind the row loads
+  constexpr bool kRegTw = (TP >= 16 && NP > 1);  // twiddle bases in registers, fetched with the row loads
 #else
   constexpr bool kRegTw = false;
 #endif
   std::conditional_t<kRegTw, RegTwiddles<T, LOG2N>, TableTwiddles<T, LOG2N>> twf;
-  if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
-  else twf.tw = reinterpret_cast<const cx<T> *>(tw);
+  if constexpr (kRegTw && PDSP_TABLES_FIRST) {
+    twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+    load_order_fence();
+  }
+  static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
+  if constexpr (kRegTw && !PDSP_TABLES_FIRST) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  if constexpr (!kRegTw) twf.tw = reinterpret_cast<const cx<T> *>(tw);
   fft_passes<T, LOG2N, false>(x, lrow, twf, tid);
   if (live) {
     static_for<E>([&](auto q) { st(row, TP * q, tid, x[q]); });
@@ -872,6 +888,20 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   // buildFrame + applyWindow (spectrum.ts:36-43, :116-119) on load; m = tid + TP*q
   const T *const xrow = frames + (size_t)row * (size_t)stride;
   cx<T> x[E];
+  // tables first (PDSP_TABLES_FIRST): twiddle bases, the split twiddle, the thread's window values
+  constexpr bool kRegTw = (LOG2E == 4 && TP >= 16);
+  std::conditional_t<kRegTw, RegTwiddles<T, LOG2M, LOG2E>, TableTwiddles<T, LOG2M, LOG2E>> twf;
+  cx<T> twk0;
+  cx<T> wv[(HAS_WIN && PDSP_TABLES_FIRST) ? E : 1];
+  if constexpr (PDSP_TABLES_FIRST) {
+    if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+    twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
+    if constexpr (HAS_WIN) {
+      const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
+      static_for<E>([&](auto q) { wv[q] = (w2 + TP * q)[(unsigned)tid]; });
+    }
+    load_order_fence();
+  }
   if constexpr (FAST) {
     const cx<T> *const x2 = reinterpret_cast<const cx<T> *>(xrow);
     static_for<E>([&](auto q) { x[q] = ld_stream(x2 + TP * q + (unsigned)tid); });
@@ -886,16 +916,19 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     });
   }
   PDSP_STAMP_INIT();
-  // twiddle bases: issued right behind the frame loads, consumed passes later
-  constexpr bool kRegTw = (LOG2E == 4 && TP >= 16);
-  std::conditional_t<kRegTw, RegTwiddles<T, LOG2M, LOG2E>, TableTwiddles<T, LOG2M, LOG2E>> twf;
-  if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
-  else twf.tw = reinterpret_cast<const cx<T> *>(tw);
-  // W_N^tid: the Hermitian split needs W_N^(tid + TP*q) = twk0 * W32^q (N = 32*TP)
-  const cx<T> twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
-  if constexpr (HAS_WIN) {
-    const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
-    static_for<E>([&](auto q) { x[q] = x[q] * (w2 + TP * q)[(unsigned)tid]; });
+  if constexpr (!kRegTw) twf.tw = reinterpret_cast<const cx<T> *>(tw);
+  if constexpr (PDSP_TABLES_FIRST) {
+    load_order_fence();
+    if constexpr (HAS_WIN) static_for<E>([&](auto q) { x[q] = x[q] * wv[q]; });
+  } else {
+    // round-1 order: twiddle bases right behind the frame loads, consumed passes later
+    if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+    // W_N^tid: the Hermitian split needs W_N^(tid + TP*q) = twk0 * W32^q (N = 32*TP)
+    twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
+    if constexpr (HAS_WIN) {
+      const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
+      static_for<E>([&](auto q) { x[q] = x[q] * (w2 + TP * q)[(unsigned)tid]; });
+    }
   }
 #ifdef PDSP_STAMPS
   pin_regs<T, E>(x);  // land the frame + window here
@@ -1331,6 +1364,14 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
 
   const V4 *const r4 = reinterpret_cast<const V4 *>(ld.plane_re() + (size_t)row * N);
   cx<T> a[E], b[E], c[E], d[E];
+  RegTwiddles<T, LOG2S> twf;
+  const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
+  cx<T> w1, w2, w3;
+  if constexpr (PDSP_TABLES_FIRST) {
+    twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
+    w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
+    load_order_fence();
+  }
   if constexpr (LD::kHasIm) {
     const V4 *const i4 = reinterpret_cast<const V4 *>(ld.plane_im() + (size_t)row * N);
     static_for<E>([&](auto q) {
@@ -1350,10 +1391,10 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
       d[q] = cx<T>{r.w, T(0)};
     });
   }
-  RegTwiddles<T, LOG2S> twf;
-  twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
-  const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
-  const cx<T> w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
+  if constexpr (!PDSP_TABLES_FIRST) {
+    twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
+    w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
+  }
 
   fft_passes<T, LOG2S, false>(a, lds, twf, tid);  // a[e] = F0[tid + TP*e]
   __syncthreads();                               // the buffer is reused by the next transform
@@ -1398,6 +1439,17 @@ fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
 
   const cx<T> *const r2 = reinterpret_cast<const cx<T> *>(ld.plane_re() + (size_t)row * N);
   cx<T> a[E], b[E];
+  // f64 complex rows: 64 data registers + 24 twiddle-base registers + the butterfly's temporaries do not
+  // fit 256 VGPRs (81 spilled); reading the twiddles from the L2-resident table at each use instead
+  // measured 4.36 -> 5.80 TB/s.  f64 real rows fit (and measure 5.6 vs 5.35 with the bases in registers).
+  constexpr bool kTableTw = sizeof(T) == 8 && LD::kHasIm;
+  std::conditional_t<kTableTw, TableTwiddles<T, 12>, RegTwiddles<T, 12>> twf;
+  cx<T> w1;
+  if constexpr (PDSP_TABLES_FIRST) {
+    if constexpr (!kTableTw) twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
+    w1 = reinterpret_cast<const cx<T> *>(tws)[(unsigned)tid];
+    load_order_fence();
+  }
   if constexpr (LD::kHasIm) {
     const cx<T> *const i2 = reinterpret_cast<const cx<T> *>(ld.plane_im() + (size_t)row * N);
     static_for<E>([&](auto q) {
@@ -1413,14 +1465,11 @@ fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
       b[q] = cx<T>{r.y, T(0)};
     });
   }
-  // f64 complex rows: 64 data registers + 24 twiddle-base registers + the butterfly's temporaries do not
-  // fit 256 VGPRs (81 spilled); reading the twiddles from the L2-resident table at each use instead
-  // measured 4.36 -> 5.80 TB/s.  f64 real rows fit (and measure 5.6 vs 5.35 with the bases in registers).
-  constexpr bool kTableTw = sizeof(T) == 8 && LD::kHasIm;
-  std::conditional_t<kTableTw, TableTwiddles<T, 12>, RegTwiddles<T, 12>> twf;
   if constexpr (kTableTw) twf.tw = reinterpret_cast<const cx<T> *>(tw12);
-  else twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
-  const cx<T> w1 = reinterpret_cast<const cx<T> *>(tws)[(unsigned)tid];
+  if constexpr (!PDSP_TABLES_FIRST) {
+    if constexpr (!kTableTw) twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
+    w1 = reinterpret_cast<const cx<T> *>(tws)[(unsigned)tid];
+  }
 
   fft_passes<T, 12, false>(a, lds, twf, tid);  // a[e] = E[tid + 256e]
   __syncthreads();                            // the buffer is reused by the second transform
@@ -1434,29 +1483,56 @@ fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   });
 }
 
-// spectrum() body for N = 16384 real frames, the config-4 shape (whole 16-byte-aligned frames,
-// one-sided amplitude, optional fused findPeak), re-cut so that FOUR frames fit a CU.
-// The packed transform Z = FFT_8192(z), z[m] = x[2m] + i*x[2m+1], is taken as one radix-2
-// decimation-in-time step over two 4096-point transforms that the SAME 256 threads run back
-// to back through one 4096-point LDS buffer:
-//   one 16-byte load gives (z[2m], z[2m+1]) = (even[m], odd[m]);  Ev = FFT_4096(even),
-//   Od = FFT_4096(odd);  Z[k] = Ev[k] + W_8192^k Od[k],  Z[k+4096] = Ev[k] - W_8192^k Od[k]
-//   in registers (thread tid holds k = tid + 256q of both).
-// The Hermitian split pairs Z[k] (k < 4096, in registers) with Z[8192-k] (upper half), so only
-// the upper half goes through LDS, once.  Versus spectrum_packed_kernel<13>: 34.8 KB instead of
-// 69.6 KB of LDS (4 workgroups per CU instead of 2, 4-wave instead of 8-wave barriers) and 2.5
-// instead of 5 full-size LDS round trips per frame.
-#ifndef PDSP_SPLIT16K_WAVES
-#define PDSP_SPLIT16K_WAVES 3  // 3 workgroups per CU (153 VGPRs fit the 168 budget; +1 % over 2, tools/kbench)
+#ifndef PDSP_DIF16K_WAVES
+#define PDSP_DIF16K_WAVES 3  // three workgroups per CU (~160 VGPRs fit the 168 budget)
 #endif
-template <typename T, bool HAS_WIN, bool PEAK>
-__global__ void __launch_bounds__(256, PDSP_SPLIT16K_WAVES)
-spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, const long long stride,
-                         const typename vec2<T>::type *__restrict__ tw12,
-                         const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp, const T s_edge,
-                         const T s_mid, PeakRec *__restrict__ peaks, const T freq_scale, const long long batch) {
+// spectrum() body for N = 16384 real frames, the config-4 shape (whole 8-byte-aligned frames, one-sided
+// amplitude, optional fused findPeak), cut so that THREE frames fit a CU: the packed transform
+// Z = FFT_8192(z), z[m] = x[2m] + i*x[2m+1], is one radix-2 decimation-in-FREQUENCY step over two
+// 4096-point transforms that the same 256 threads run back to back through one 4096-point LDS buffer
+// (spectrum_packed_kernel<13> needs 69.6 KB of LDS per frame and 5 full-size LDS round trips; here
+// 34.8 KB and 2.5).  Round 1 made the cut by decimation in TIME (16-byte loads, Z[k] / Z[k+4096] in
+// registers, dword stores): same arithmetic, 5.05 TB/s; this cut: 5.7 (fused Hann window).
+//   u[m] = z[m] + z[m+4096],  v[m] = (z[m] - z[m+4096]) * W_8192^m,   m < 4096;
+//   U = FFT_4096(u) = the even bins Z[2k],  V = FFT_4096(v) = the odd bins Z[2k+1].
+// The radix-2 step sits in front of the sub-transforms, which shapes the memory accesses at both ends
+// (tools/kbench2: the load / store skeleton of this shape runs at 5.9-6.0 TB/s against 5.5-5.6 for the
+// decimation-in-time shape, on a part whose 2:1 read:write copy tops out at 6.1-6.3):
+//   * a thread needs z[m] and z[m+4096], m = tid + 256q: plain 8-byte loads at unit stride across the
+//     lanes (32 per thread) instead of 16-byte loads that drag two sub-sequences along;
+//   * the Hermitian split pairs Z[j] with Z[8192-j]: even with even, odd with odd, so thread tid ends up
+//     owning bins (2k, 2k+1) and their mirrors (8191-2k, 8192-2k), k = tid + 256q, q < 8 -- ADJACENT
+//     bins: 16 non-temporal 8-byte stores per thread instead of 33 dword stores in two directions.
+//     (Non-temporal matters: plain 8-byte stores measured 5.4, non-temporal 6.0 TB/s; dword stores are
+//     the other way round because a wave's 256 unaligned bytes are completed by its neighbours in L2.)
+//   * partners: U[4096-k] and V[4095-k] live in the upper eight registers of thread 256-tid / 255-tid:
+//     every thread parks its upper eight U and V values in LDS (32 KB, unit stride, no padding needed)
+//     and reads eight of each back, lanes reversed.
+// 34.8 KB of LDS (the sub-transforms' exchange buffer), three workgroups per CU.
+//   tw12 = radix table of the 4096-point transform; twr[k] = W_16384^k, k <= 4096.
+//   WIN: 0 = rect; 1 = window table (N values, 8-byte loads: 64 KB of L2 reads per frame -- measured
+//   11 % of the kernel's time, 5.32 vs 5.97 TB/s); 2 / 3 = createWindow FUSED (fourier.ts:14-52): the
+//   reference's windows are cosine sums a0 - a1 cos(f n) + a2 cos(2 f n), f = 2 pi / (N - 1), and a
+//   thread's sample indices are n = (2 tid + e) + 512 q (+ 8192), so cos(f n) is one angle addition from
+//   a per-thread base (one 16-byte load: cos / sin of f (2 tid + e), e = 0, 1) and a per-q constant
+//   (wave-uniform: scalar loads): 3-4 packed instructions per pair of samples and no table traffic.
+//   wcoef = (a0 - a2, -a1, 2 a2): w = k0 + c (k1 + k2 c) with c = cos(f n)  [cos 2x = 2 c^2 - 1].
+//   Values agree with the f64-built, f32-rounded table to ~2e-7 absolute.
+struct WinFused {
+  const float *base;  // [256][4]: cos, sin of f*(2 tid), cos, sin of f*(2 tid + 1)
+  const float *step;  // [32][2]: cos, sin of f*512 q (q < 16), then of f*(512 q + 8192)
+  float k0, k1, k2;
+};
+template <typename T, int WIN, bool PEAK>
+__global__ void __launch_bounds__(256, PDSP_DIF16K_WAVES)
+spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, const WinFused wf, const long long stride,
+                       const typename vec2<T>::type *__restrict__ tw12,
+                       const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp, const T s_edge,
+                       const T s_mid, PeakRec *__restrict__ peaks, const T freq_scale, const long long batch) {
+  constexpr bool HAS_WIN = WIN == 1;
+  static_assert(WIN <= 1 || sizeof(T) == 4, "the fused window is the f32 path's (f64 keeps the f64-built table)");
   using TR = FftTraits<12>;
-  constexpr int E = 16, TP = 256, H = 4096, M = 8192;
+  constexpr int E = 16, TP = 256, H = 4096, M = 8192, Q = 2048;
   typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ cx<T> lds[TR::LROW];
 
@@ -1464,103 +1540,128 @@ spectrum_split16k_kernel(const T *__restrict__ frames, const T *__restrict__ win
   const long long row = uniform_row<TP>((long long)blockIdx.x);
   if (row >= batch) return;
   const cx<T> *const tw = reinterpret_cast<const cx<T> *>(tw12);
-  const cx<T> *const twn = reinterpret_cast<const cx<T> *>(twr);  // W_16384^k, k <= 4096
 
-  // one 16-byte load per point pair; m = tid + 256*q
-  const V4 *const x4 = reinterpret_cast<const V4 *>(frames + (size_t)row * (size_t)stride);
-  cx<T> a[E], b[E];
-  static_for<E>([&](auto q) {
-    const V4 v = ld_stream(x4 + TP * q + (unsigned)tid);
-    a[q] = cx<T>{v.x, v.y};
-    b[q] = cx<T>{v.z, v.w};
-  });
-  // twiddle bases right behind the frame loads (see RegTwiddles)
+  // tables first (PDSP_TABLES_FIRST): twiddle bases, the two split bases, the thread's window values
   RegTwiddles<T, 12> twf;
   twf.load(tw, tid);
-  const cx<T> wc0 = twn[(unsigned)(2 * tid)];  // W_8192^tid  (combine: W_8192^(tid+256q) = wc0 * W32^q)
-  const cx<T> ws0 = twn[(unsigned)tid];        // W_16384^tid (split:   W_16384^(tid+256q) = ws0 * W64^q)
+  // (W_16384^(2 tid), W_16384^(2 tid + 1)) in one 16-byte load: the first is W_8192^tid, base of the
+  // decimation twiddle W_8192^(tid+256q) = wc0 * W32^q AND of the even bins' split twiddle W_16384^(2k);
+  // the second is the base of the odd bins' W_16384^(2k+1) = ws1 * W32^q
+  const V4 wcs = reinterpret_cast<const V4 *>(twr)[(unsigned)tid];
+  const cx<T> wc0{wcs.x, wcs.y}, ws1{wcs.z, wcs.w};
+  cx<T> wlo[HAS_WIN ? E : 1], whi[HAS_WIN ? E : 1];
   if constexpr (HAS_WIN) {
-    const V4 *const w4 = reinterpret_cast<const V4 *>(win);
+    const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
     static_for<E>([&](auto q) {
-      const V4 w = (w4 + TP * q)[(unsigned)tid];
-      a[q] = a[q] * cx<T>{w.x, w.y};
-      b[q] = b[q] * cx<T>{w.z, w.w};
+      wlo[q] = (w2 + TP * q)[(unsigned)tid];
+      whi[q] = (w2 + H + TP * q)[(unsigned)tid];
     });
   }
+  V4 wb4 = V4{T(0), T(0), T(0), T(0)};
+  if constexpr (WIN >= 2) wb4 = reinterpret_cast<const V4 *>(wf.base)[(unsigned)tid];
+  load_order_fence();
 
-  PDSP_STAMP_INIT();
-#ifdef PDSP_STAMPS
-  pin_regs<T, E>(a);  // land the frame + window here
-  pin_regs<T, E>(b);
-#endif
-  PDSP_STAMP(32);  // wait for the frame + window loads
-  fft_passes<T, 12, false>(a, lds, twf, tid);  // a[q] = Ev[tid + 256q]
-  __syncthreads();                            // the buffer is reused by the second transform
-  PDSP_STAMP(33);  // first sub-transform
-  fft_passes<T, 12, false>(b, lds, twf, tid);  // b[q] = Od[tid + 256q]
-  PDSP_STAMP(34);  // second sub-transform
-
-  // radix-2 combine in registers: a <- Z[k], b <- Z[k + 4096]
+  // z[m], z[m + 4096], m = tid + 256q: 8-byte non-temporal loads, unit stride across the lanes
+  const cx<T> *const z2 = reinterpret_cast<const cx<T> *>(frames + (size_t)row * (size_t)stride);
+  cx<T> a[E], b[E];
   static_for<E>([&](auto q) {
-    const cx<T> t = cmul(b[q], mul_w32<T, q>(wc0));
-    b[q] = a[q] - t;
-    a[q] = a[q] + t;
+    a[q] = ld_stream(z2 + TP * q + (unsigned)tid);
+    b[q] = ld_stream(z2 + H + TP * q + (unsigned)tid);
   });
-  // upper half -> LDS (natural order) for the partners Z[8192 - k]
-  __syncthreads();
-  {
-    cx<T> *const wbase = lds + lds_pad(tid);
-    static_for<E>([&](auto q) { wbase[cpad(TP * q)] = b[q]; });
+  load_order_fence();
+  if constexpr (HAS_WIN) {
+    static_for<E>([&](auto q) {
+      a[q] = a[q] * wlo[q];
+      b[q] = b[q] * whi[q];
+    });
   }
+  if constexpr (WIN >= 2) {
+    const cx<T> cb{wb4.x, wb4.z}, sb{wb4.y, wb4.w};  // (e = 0, e = 1)
+    const T k0 = wf.k0, k1 = wf.k1, k2 = wf.k2;
+    static_for<E>([&](auto qc) {
+      constexpr int q = qc;
+      const T cl = wf.step[2 * q], sl = wf.step[2 * q + 1], ch = wf.step[32 + 2 * q], sh = wf.step[32 + 2 * q + 1];
+      const cx<T> c_lo = cb * cl - sb * sl, c_hi = cb * ch - sb * sh;  // cos(f n), n = 2m + e and + 8192
+      if constexpr (WIN == 3) {
+        a[q] = a[q] * (k0 + c_lo * (k1 + k2 * c_lo));
+        b[q] = b[q] * (k0 + c_hi * (k1 + k2 * c_hi));
+      } else {
+        a[q] = a[q] * (k0 + k1 * c_lo);
+        b[q] = b[q] * (k0 + k1 * c_hi);
+      }
+    });
+  }
+  // decimation in frequency: a <- u, b <- v
+  static_for<E>([&](auto q) {
+    const cx<T> d = a[q] - b[q];
+    a[q] = a[q] + b[q];
+    b[q] = cmul(d, mul_w32<T, q>(wc0));
+  });
+
+  fft_passes<T, 12, false>(a, lds, twf, tid);  // a[q] = U[tid + 256q] = Z[2(tid + 256q)]
+  __syncthreads();                            // the buffer is reused by the second transform
+  fft_passes<T, 12, false>(b, lds, twf, tid);  // b[q] = V[tid + 256q] = Z[2(tid + 256q) + 1]
+
+  // upper halves (k >= 2048) -> LDS: U[k] at k - 2048, V[k] at 2048 + (k - 2048)
   __syncthreads();
-  PDSP_STAMP(35);  // combine + upper half through LDS
+  static_for<E / 2>([&](auto q) {
+    lds[tid + TP * q] = a[q + E / 2];
+    lds[Q + tid + TP * q] = b[q + E / 2];
+  });
+  const cx<T> umid = a[E / 2];  // thread 0: U[2048] = Z[4096], the bin that pairs with itself
+  __syncthreads();
 
   T *const arow = amp + (size_t)row * (size_t)(M + 1);
   const bool store_amp = !PEAK || amp != nullptr;
   PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);
   cx<T> dc_x{T(0), T(0)};
-  // pairs (k, 8192-k), k = tid + 256q < 4096.  Partner Z[8192-k] = upper[4096-k] for k >= 1;
-  // k = 0 pairs with itself (DC and Nyquist).  upper[4096-k] sits at pad(4096 - tid) - q*cpad(256).
-  const cx<T> *const uhi = lds + lds_pad(H - tid);
-  static_for<E>([&](auto qc) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  static_for<E / 2>([&](auto qc) {
     constexpr int q = qc;
-    const int k = tid + TP * q;
-    const cx<T> z = a[q];
-    cx<T> zp;
-    if constexpr (q == 0) zp = tid == 0 ? z : uhi[0];
-    else zp = *(uhi - cpad(TP * q));
-    const cx<T> w = mul_w64<T, q>(ws0);                  // W_N^k
-    // the amplitude scale rides on the 1/2 of the split (DC and Nyquist, k = 0, are not doubled); a
-    // positive scale leaves the phase of the peak untouched
-    const T h = T(0.5) * ((k == 0) ? s_edge : s_mid);
-    const cx<T> e = (z + conj(zp)) * h;
-    const cx<T> p = cmul(z - conj(zp), w) * h;           // i * W * O, O = (Z - conj Zp)/(2i)
-    const cx<T> xa = add_mul_neg_i(e, p);                // scaled X[k] = E + W*O
-    const cx<T> xb = conj(add_mul_pos_i(e, p));          // scaled X[8192 - k] = conj(E - W*O)
-    const T ma = mag(xa), mb = mag(xb);
+    const int k = tid + TP * q;  // < 2048
+    // even bins: Z[2k] = U[k] with Z[8192 - 2k] = U[4096 - k] (k = 0: DC and Nyquist, paired with itself)
+    const cx<T> ze = a[q];
+    cx<T> zpe;
+    if constexpr (q == 0) zpe = tid == 0 ? ze : lds[Q - tid];
+    else zpe = lds[Q - TP * q - tid];
+    // odd bins: Z[2k+1] = V[k] with Z[8191 - 2k] = V[4095 - k]
+    const cx<T> zo = b[q];
+    const cx<T> zpo = lds[Q + (Q - 1) - TP * q - tid];
+    const cx<T> we = mul_w32<T, q>(wc0);  // W_16384^(2k)
+    const cx<T> wo = mul_w32<T, q>(ws1);  // W_16384^(2k+1)
+    // the amplitude scale rides on the 1/2 of the split (DC and Nyquist, k = 0, are not doubled)
+    const T he = T(0.5) * ((k == 0) ? s_edge : s_mid), ho = T(0.5) * s_mid;
+    const cx<T> ee = (ze + conj(zpe)) * he, pe = cmul(ze - conj(zpe), we) * he;
+    const cx<T> eo = (zo + conj(zpo)) * ho, po = cmul(zo - conj(zpo), wo) * ho;
+    const cx<T> xae = add_mul_neg_i(ee, pe);        // scaled X[2k]
+    const cx<T> xbe = conj(add_mul_pos_i(ee, pe));  // scaled X[8192 - 2k]
+    const cx<T> xao = add_mul_neg_i(eo, po);        // scaled X[2k + 1]
+    const cx<T> xbo = conj(add_mul_pos_i(eo, po));  // scaled X[8191 - 2k]
+    const T mae = mag(xae), mbe = mag(xbe), mao = mag(xao), mbo = mag(xbo);
     if constexpr (PEAK) {
       if (k == 0) {
-        dc_amp = ma;
-        dc_x = xa;
+        dc_amp = mae;
+        dc_x = xae;
       } else {
-        best.consider(ma, k, xa);
+        best.consider(mae, 2 * k, xae);
       }
-      best.consider(mb, M - k, xb);
+      best.consider(mao, 2 * k + 1, xao);
+      best.consider(mbo, M - 1 - 2 * k, xbo);
+      best.consider(mbe, M - 2 * k, xbe);
     }
     if (store_amp) {
-      st_rowtail(ma, arow + (unsigned)k);
-      st_rowtail(mb, arow + (unsigned)(M - k));
+      __builtin_nontemporal_store(V2{mae, mao}, reinterpret_cast<V2 *>(arow + (unsigned)(2 * k)));
+      __builtin_nontemporal_store(V2{mbo, mbe}, reinterpret_cast<V2 *>(arow + (unsigned)(M - 1 - 2 * k)));
     }
   });
-  // the middle bin k = 4096 pairs with itself: X[4096] = conj(Z[4096]) = conj(upper[0]) (thread 0's b[0])
+  // the middle bin 4096 = 2*2048 pairs with itself: X[4096] = conj(Z[4096]) = conj(U[2048])
   if (tid == 0) {
-    const cx<T> xm = conj(b[0]);
+    const cx<T> xm = conj(umid);
     const T mm = mag(xm) * s_mid;
     if constexpr (PEAK) best.consider(mm, H, xm);
     if (store_amp) st_rowtail(mm, arow + (unsigned)H);
   }
-  PDSP_STAMP(36);  // Hermitian split + magnitude + stores issued
 
   if constexpr (PEAK) {
     static_for<6>([&](auto sc) {

@@ -115,13 +115,18 @@ def test_spectrum_full_size_properties():
     assert float(((amp3 - 3 * amp).abs().amax(dim=1) / amp3.amax(dim=1)).max()) < 1e-6
 
 
-@pytest.mark.parametrize("window", ["rect", "hann"])
-def test_split16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, window):
-    """N = 16384 whole aligned frames run on spectrum_split16k_kernel (two 4096-point sub-transforms
-    per workgroup); pdsp_set_split16k(0) routes the same call to spectrum_packed_kernel<13>."""
+@pytest.mark.parametrize("window", ["rect", "hann", "hamming", "blackman", "custom"])
+def test_dif16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, window):
+    """N = 16384 whole pair-aligned frames run on spectrum_dif16k_kernel (two 4096-point sub-transforms
+    per workgroup, decimation in frequency on top, 8-byte non-temporal stores of adjacent bins);
+    pdsp_set_split16k(0) routes the same call to spectrum_packed_kernel<13>.  A window named by kind is
+    the plan's own table, so createWindow is FUSED into the kernel (cosine sum in registers);
+    pdsp_set_fused_window(0) makes the kernel read the table instead, and a caller's own tensor
+    ("custom": a Hann table plus a ripple) is always read as a table.  All against the oracle, plus guard
+    cells behind the rows (the 8-byte stores of the last row must not run over)."""
     import torch
     from pragma_dsp_amd.batch import BatchedFft
-    n = 16384
+    n, bins = 16384, 8193
     rng = np.random.default_rng(16)
     t = np.arange(n)
     x = (rng.standard_normal((9, n)) * 0.3 + np.sin(2 * np.pi * 777 * t / n)[None, :]).astype(np.float32)
@@ -129,28 +134,75 @@ def test_split16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, wind
     x[8] = 1.0          # DC: peak stays at bin 0
     dx = torch.from_numpy(x).cuda()
     plan = BatchedFft(n, "cuda:0")
-    win = oracle_mod.create_window(window, n).astype(np.float32) if window != "rect" else None
+    if window == "custom":
+        win = (oracle_mod.create_window("hann", n) * (1 + 0.1 * np.cos(0.01 * t))).astype(np.float32)
+        warg = torch.from_numpy(win).cuda()
+    else:
+        win = oracle_mod.create_window(window, n).astype(np.float32) if window != "rect" else None
+        warg = window
     wamp, _, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, want_peak=True)
     res = {}
-    for mode in (1, 0):
-        prev = pdsp.lib.pdsp_set_split16k(mode)
+    for mode in ((1, 1), (1, 0), (0, 1)):   # (dif16k kernel, fused window)
+        prev = pdsp.lib.pdsp_set_split16k(mode[0])
+        prevf = pdsp.lib.pdsp_set_fused_window(mode[1])
         try:
-            amp, _, pki = plan.spectrum(dx, window, "one", want_peak=True)   # peak-index array (common tail)
+            buf = torch.full((9 * bins + 64,), -7.0, device="cuda")
+            out = buf[:9 * bins].view(9, bins)
+            amp, _, pki = plan.spectrum(dx, warg, "one", want_peak=True, out=out)   # peak-index array (common tail)
             assert list(pki.cpu().numpy()[:7]) == [777] * 7 and int(pki[7]) == 0
-            idx, freq, pamp, pph, _, _ = plan.spectrum_peaks(dx, window, "one", 48000.0)
+            idx, freq, pamp, pph, _, _ = plan.spectrum_peaks(dx, warg, "one", 48000.0)
             torch.cuda.synchronize()
         finally:
             pdsp.lib.pdsp_set_split16k(prev)
+            pdsp.lib.pdsp_set_fused_window(prevf)
+        assert bool((buf[9 * bins:] == -7.0).all())
         res[mode] = (amp.cpu().numpy(), idx.cpu().numpy(), pamp.cpu().numpy(), pph.cpu().numpy())
         assert rel_err(res[mode][0][:7], wamp[:7]) <= TOL
         assert not res[mode][0][7].any() and res[mode][1][7] == 0 and res[mode][2][7] == 0
-        # DC frame: bin 0 with a rect window; with Hann the window's own bin 1 wins (findPeak skips DC)
+        # DC frame: bin 0 with a rect window; with a tapering window the window's own bin 1 wins (findPeak skips DC)
         assert res[mode][1][8] == wpk[8] == (0 if window == "rect" else 1)
         assert abs(res[mode][2][8] - wamp[8, wpk[8]]) < 1e-5
         assert list(res[mode][1][:7]) == list(wpk[:7]) == [777] * 7
         assert np.array_equal(res[mode][0][np.arange(7), res[mode][1][:7]], res[mode][2][:7])
-    assert rel_err(res[1][0][:7], res[0][0][:7]) <= 2e-6          # the two kernels agree to rounding
-    assert np.abs(((res[1][3][:7] - res[0][3][:7]) + np.pi) % (2 * np.pi) - np.pi).max() < 1e-4
+    for other in ((1, 0), (0, 1)):
+        assert rel_err(res[(1, 1)][0][:7], res[other][0][:7]) <= 2e-6          # the kernels / window forms agree to rounding
+        assert np.abs(((res[(1, 1)][3][:7] - res[other][3][:7]) + np.pi) % (2 * np.pi) - np.pi).max() < 1e-4
+    if window in ("rect", "custom"):  # nothing to fuse: the same kernel variant runs either way
+        assert np.array_equal(res[(1, 1)][0], res[(1, 0)][0])
+
+
+def test_plan_window_is_create_window_and_fused_window_matches_table(pdsp, oracle_mod):
+    """pdsp_plan_window_f32: the plan's own createWindow(type, N) table, equal to the oracle's f64 window
+    rounded once to f32, for every type (and any size); the fused evaluation agrees with it to ~2e-7:
+    checked through spectrum() of an impulse train whose bins expose the window itself."""
+    import torch
+    from pragma_dsp_amd._capi import check
+    from pragma_dsp_amd.batch import BatchedFft, _ptr, _stream_ptr
+    for n in (16384, 1024, 8):
+        plan = BatchedFft(n, "cuda:0")
+        for kind in ("rect", "hann", "hamming", "blackman"):
+            w = plan.window(kind)
+            assert w.data_ptr() == plan.window(kind).data_ptr() != 0     # cached per kind
+            # read the plan's table back through the product itself: applyWindow(ones, table) = table
+            ones = torch.ones((1, n), dtype=torch.float32, device="cuda")
+            back = torch.empty_like(ones)
+            check(pdsp.lib.pdsp_apply_window_f32(1, n, _ptr(ones), _ptr(w), _ptr(back), _stream_ptr(plan.device)))
+            torch.cuda.synchronize()
+            want = oracle_mod.create_window(kind, n).astype(np.float32)
+            assert np.array_equal(back.cpu().numpy()[0], want)
+            assert np.array_equal(w.tensor().cpu().numpy(), want)
+    # fused vs table on frames that are ONE unit sample at position p: |X[k]| * N/2 = w[p] for every bin
+    n = 16384
+    plan = BatchedFft(n, "cuda:0")
+    pos = np.array([0, 1, 2, 3, 511, 512, 513, 4095, 8191, 8192, 8193, 12000, 16381, 16382, 16383])
+    x = np.zeros((len(pos), n), dtype=np.float32)
+    x[np.arange(len(pos)), pos] = 1.0
+    dx = torch.from_numpy(x).cuda()
+    for kind in ("hann", "hamming", "blackman"):
+        amp, _, _ = plan.spectrum(dx, kind, "one")
+        got = amp.cpu().numpy()[:, 5] * (n / 2)                      # any bin between DC and Nyquist
+        want = oracle_mod.create_window(kind, n)[pos]
+        assert np.abs(got - want).max() <= 5e-7, (kind, np.abs(got - want).max())
 
 
 @pytest.mark.parametrize("n,batch", [(64, 1), (64, 128), (64, 131), (128, 64), (128, 77), (256, 33), (512, 16),

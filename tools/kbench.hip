@@ -104,33 +104,94 @@ static int spec_main(long long frames, int rounds) {
   CK(hipMalloc(&dtw12, tw12.size() * 8));
   CK(hipMemcpy(dtw12, tw12.data(), tw12.size() * 8, hipMemcpyHostToDevice));
   const bool split = getenv("KB_SPLIT") != nullptr;
-  auto run = [&] {
-    if (split && getenv("KB_NOWIN")) {
-      hipLaunchKernelGGL((pdsp::spectrum_split16k_kernel<float, false, false>), dim3(frames), dim3(256), 0, 0, x, win,
-                         (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
-      return;
-    }
-    if (split) {
-      hipLaunchKernelGGL((pdsp::spectrum_split16k_kernel<float, true, false>), dim3(frames), dim3(256), 0, 0, x, win,
-                         (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
-      return;
-    }
+  struct SV {
+    const char *name;
+    std::function<void()> run;
+    std::vector<float> ms;
+  };
+  std::vector<SV> svs;
+  svs.push_back({"packed<13>", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true, false>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
                        dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
-                       1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames);
-  };
-  for (int i = 0; i < 20; ++i) run();
-  CK(hipDeviceSynchronize());
-  for (int r = 0; r < rounds; ++r) {
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; ++i) run();
-    CK(hipEventRecord(e1, 0));
-    CK(hipEventSynchronize(e1));
-    float t;
-    CK(hipEventElapsedTime(&t, e0, e1));
-    ms.push_back(t / 5);
+                       1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
+  pdsp::WinFused wfz{nullptr, nullptr, 0.f, 0.f, 0.f}, wfh = wfz;
+  {
+    const double f = 2 * M_PI / (n - 1);
+    std::vector<float> hb(256 * 4), hs(64);
+    for (int t = 0; t < 256; ++t)
+      for (int e = 0; e < 2; ++e) {
+        hb[4 * t + 2 * e] = (float)cos(f * (2 * t + e));
+        hb[4 * t + 2 * e + 1] = (float)sin(f * (2 * t + e));
+      }
+    for (int q = 0; q < 16; ++q) {
+      hs[2 * q] = (float)cos(f * 512 * q), hs[2 * q + 1] = (float)sin(f * 512 * q);
+      hs[32 + 2 * q] = (float)cos(f * (512 * q + 8192)), hs[32 + 2 * q + 1] = (float)sin(f * (512 * q + 8192));
+    }
+    float *db, *dsx;
+    CK(hipMalloc(&db, hb.size() * 4));
+    CK(hipMalloc(&dsx, hs.size() * 4));
+    CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsx, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    wfh = pdsp::WinFused{db, dsx, 0.5f, -0.5f, 0.0f};
   }
+  svs.push_back({"dif16k (x2 ld, x2 nt st)", [&] {
+    hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 1, false>), dim3(frames), dim3(256), 0, 0, x, win, wfz,
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
+  svs.push_back({"dif16k fused hann (2-term)", [&] {
+    hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 2, false>), dim3(frames), dim3(256), 0, 0, x, win, wfh,
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
+  svs.push_back({"dif16k fused 3-term (hann coefficients)", [&] {
+    hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 3, false>), dim3(frames), dim3(256), 0, 0, x, win, wfh,
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
+  svs.push_back({"dif16k rect window", [&] {
+    hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 0, false>), dim3(frames), dim3(256), 0, 0, x, win, wfz,
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
+  auto run = [&] { svs[split ? 1 : 0].run(); };
+  for (int i = 0; i < 10; ++i)
+    for (auto &v : svs) v.run();
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r)
+    for (auto &v : svs) {
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) v.run();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float t;
+      CK(hipEventElapsedTime(&t, e0, e1));
+      v.ms.push_back(t / 5);
+    }
   CK(hipGetLastError());
+  {
+    // agreement of the variants' outputs at the fp32 tolerance of the path (the parity tests proper are
+    // tests/test_gpu_spectrum.py): every dif16k variant against the packed kernel's rows
+    std::vector<float> ref((size_t)64 * bins), got((size_t)64 * bins);
+    svs[0].run();
+    CK(hipMemcpy(ref.data(), amp + (size_t)(frames - 64) * bins, ref.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t vi = 1; vi + 1 < svs.size(); ++vi) {
+      CK(hipMemset(amp, 0xff, (size_t)frames * bins * 4));
+      svs[vi].run();
+      CK(hipMemcpy(got.data(), amp + (size_t)(frames - 64) * bins, got.size() * 4, hipMemcpyDeviceToHost));
+      double worst = 0;
+      for (int r = 0; r < 64; ++r) {
+        double mx = 0, err = 0;
+        for (int i = 0; i < bins; ++i) {
+          mx = std::max(mx, (double)ref[(size_t)r * bins + i]);
+          const double d = std::fabs((double)ref[(size_t)r * bins + i] - (double)got[(size_t)r * bins + i]);
+          err = std::max(err, std::isnan(d) ? 1e30 : d);
+        }
+        worst = std::max(worst, err / mx);
+      }
+      printf("%s vs packed<13> rows: max |diff| / max = %.3e\n", svs[vi].name, worst);
+    }
+  }
+  const double sbytes = (4.0 * n + 4.0 * bins) * frames;
+  for (auto &v : svs) {
+    std::sort(v.ms.begin(), v.ms.end());
+    printf("%-44s med %.4f ms  min %.4f ms  med %.0f GB/s  max %.0f GB/s\n", v.name, v.ms[v.ms.size() / 2], v.ms[0],
+           sbytes / v.ms[v.ms.size() / 2] / 1e6, sbytes / v.ms[0] / 1e6);
+  }
+  ms = svs[1].ms;
+  (void)run;
 #ifdef PDSP_STAMPS
   {
     unsigned long long z[64] = {0}, acc[64];
