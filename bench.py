@@ -489,7 +489,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         im = None
         launches_per_step = per_gpu // chunk
         bytes_per_launch = (4 * n + 16) * chunk  # frame in, one 16-byte SpectrumPeak out
-        kernel_name = kernel_label = "spectrum_split16k_kernel<float, true, true>"
+        kernel_name = kernel_label = "spectrum_dif16k_kernel<float, 2, true>"
         plan.window("hann")
 
         def step():
@@ -505,7 +505,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         launches_per_step = per_gpu // chunk
         bytes_per_launch = (4 * n + 4 * bins) * chunk  # 98,308 B per frame
         parity_kind = "spectrum"
-        kernel_name = kernel_label = "spectrum_split16k_kernel<float, true, false>"
+        kernel_name = kernel_label = "spectrum_dif16k_kernel<float, 2, false>"
         if args.workload == "spectrum256":
             kernel_name = kernel_label = "spectrum_staged_kernel<float, 7, true>" if n == 256 else f"spectrum kernel of N={n}"
         plan.window("hann")
@@ -713,7 +713,7 @@ def also_spectrum16k(args, dev, rank: int):
     nbytes = (4 * n + 4 * (n // 2 + 1)) * chunk
     avg = float(np.mean(ms))
     res = {"config": "N=16384 fused hann+FFT+one-sided amplitude, one 16384-frame chunk (configs[3] shape)",
-           "kernel": "spectrum_split16k_kernel<float, true, false>", "steps": steps, "ms": avg, "ms_min": float(np.min(ms)),
+           "kernel": "spectrum_dif16k_kernel<float, 2, false> (fused Hann)", "steps": steps, "ms": avg, "ms_min": float(np.min(ms)),
            "GSample_per_s": chunk * n / (avg * 1e-3) / 1e9, "algorithmic_bytes_per_launch": nbytes,
            "GBps": nbytes / (avg * 1e-3) / 1e9, "frac": nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     if not args.no_cpu_baseline:

@@ -21,7 +21,8 @@ except ImportError:  # pure drop-in use without torch: the system runtime is the
     pass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpdsp_hip.so")
+# PDSP_LIB_PATH: another build of the same library (development A/B runs of compile-time kernel options)
+LIB_PATH = os.environ.get("PDSP_LIB_PATH") or os.path.join(_HERE, "csrc", "libpdsp_hip.so")
 
 # pdsp_status
 OK = 0

@@ -288,10 +288,17 @@ __device__ __forceinline__ long long uniform_row(long long row) {
 // twiddles, window values) are requested BEFORE its streamed row (HBM).  The memory counter retires in
 // issue order and the vector-memory pipeline is a queue: table loads issued behind the row loads sit
 // behind 16-64 KB of streaming requests and their data is not usable until every older HBM load is back.
-// Round 1 issued them "right behind the row loads"; measured on the N=16384 spectrum kernel
-// 5.07-5.12 -> 5.40 TB/s (tools/kbench spec).  0 restores the round-1 order for A/B runs.
+// Round 1 issued them "right behind the row loads".  Measured A/B (tools/kbench, tools/sweep.py with
+// PDSP_LIB_PATH): the fused spectrum kernels, which carry a window's worth of table loads, gain
+// (N=16384 decimation-in-time kernel 5.07-5.12 -> 5.40 TB/s; packed kernel N=1024 / 2048 / 4096 / 8192
+// +3 / +4 / +1 / +1 %), the N=16384 complex kernel gains +2...7 %; the plain transforms, whose only
+// tables are 12-14 twiddle bases, LOSE 1 % (complex) to 3.5 % (real input) -- there the bases stay
+// behind the row loads (PDSP_TABLES_FIRST_C2C 0).  0 / 1 are compile-time A/B switches.
 #ifndef PDSP_TABLES_FIRST
-#define PDSP_TABLES_FIRST 1
+#define PDSP_TABLES_FIRST 1      /* spectrum_packed_kernel, fft_split4_kernel, fft_split2_kernel */
+#endif
+#ifndef PDSP_TABLES_FIRST_C2C
+#define PDSP_TABLES_FIRST_C2C 0  /* fft_stockham_kernel */
 #endif
 __device__ __forceinline__ void load_order_fence() { __builtin_amdgcn_sched_barrier(0); }
 
@@ -671,12 +678,12 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
   constexpr bool kRegTw = false;
 #endif
   std::conditional_t<kRegTw, RegTwiddles<T, LOG2N>, TableTwiddles<T, LOG2N>> twf;
-  if constexpr (kRegTw && PDSP_TABLES_FIRST) {
+  if constexpr (kRegTw && PDSP_TABLES_FIRST_C2C) {
     twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
     load_order_fence();
   }
   static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
-  if constexpr (kRegTw && !PDSP_TABLES_FIRST) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  if constexpr (kRegTw && !PDSP_TABLES_FIRST_C2C) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
   if constexpr (!kRegTw) twf.tw = reinterpret_cast<const cx<T> *>(tw);
   fft_passes<T, LOG2N, false>(x, lrow, twf, tid);
   if (live) {

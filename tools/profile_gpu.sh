@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also $*"
 # 1. per-kernel time (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || exit 1
 # 2./3. HBM bytes: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slot budget)
