@@ -235,16 +235,16 @@ hipError_t launch_rows(const Tables<T> &t, int log2n, const LD &ld, const ST &st
 
 
 template <typename T, int LOG2M>
-hipError_t launch_packed_one(bool fast, const T *frames, const T *win, long long frame_len, long long stride,
-                             const typename pdsp::vec2<T>::type *tw, const typename pdsp::vec2<T>::type *twr, T *amp,
-                             T *ph, int two_sided, T s_edge, T s_mid, pdsp::PeakRec *peaks, T freq_scale,
-                             long long batch, hipStream_t s) {
+hipError_t launch_packed_one(bool fast, const T *frames, const T *win, int wmode, pdsp::WinFused wf, long long frame_len,
+                             long long stride, const typename pdsp::vec2<T>::type *tw,
+                             const typename pdsp::vec2<T>::type *twr, T *amp, T *ph, int two_sided, T s_edge, T s_mid,
+                             pdsp::PeakRec *peaks, T freq_scale, long long batch, hipStream_t s) {
   using TR = pdsp::FftTraits<LOG2M, pdsp::packed_log2e(LOG2M)>;
   const long long ngroups = (batch + TR::ROWS - 1) / TR::ROWS;
   const dim3 block(TR::WG);
 #define PDSP_LAUNCH(F, W, P)                                                                                  \
   hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<T, LOG2M, F, W, P>), dim3((unsigned)ngroups), block, 0, s, \
-                     frames, win, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, peaks, freq_scale, \
+                     frames, win, wf, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, peaks, freq_scale, \
                      batch)
 #define PDSP_LAUNCH_FW(F, W)                            \
   do {                                                  \
@@ -255,10 +255,22 @@ hipError_t launch_packed_one(bool fast, const T *frames, const T *win, long long
       PDSP_LAUNCH(F, W, false); /* fused peaks: f32 only */ \
     }                                                   \
   } while (0)
-  if (fast && win) PDSP_LAUNCH_FW(true, true);
-  else if (fast) PDSP_LAUNCH_FW(true, false);
-  else if (win) PDSP_LAUNCH_FW(false, true);
-  else PDSP_LAUNCH_FW(false, false);
+  // fused cosine-sum windows (wmode 2 / 3): whole f32 frames of N = 1024 ... 8192 (the sizes whose plans
+  // carry the angle-addition tables); everything else reads the window as a table
+  if constexpr (sizeof(T) == 4 && LOG2M >= 9 && LOG2M <= 12) {
+    if (fast && wmode == 2) {
+      PDSP_LAUNCH_FW(true, 2);
+      return hipGetLastError();
+    }
+    if (fast && wmode == 3) {
+      PDSP_LAUNCH_FW(true, 3);
+      return hipGetLastError();
+    }
+  }
+  if (fast && win) PDSP_LAUNCH_FW(true, 1);
+  else if (fast) PDSP_LAUNCH_FW(true, 0);
+  else if (win) PDSP_LAUNCH_FW(false, 1);
+  else PDSP_LAUNCH_FW(false, 0);
 #undef PDSP_LAUNCH_FW
 #undef PDSP_LAUNCH
   return hipGetLastError();
@@ -824,6 +836,25 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
       e = hipMalloc((void **)&t.tw12, t12.size() * sizeof(T2));
       if (e == hipSuccess) e = hipMemcpy(t.tw12, t12.data(), t12.size() * sizeof(T2), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && log2n >= 10 && log2n <= 13 && sizeof(T) == 4) {
+      // fused createWindow for spectrum_packed_kernel (N = 1024 ... 8192): sample n = (2 tid + e) + 2 TP q
+      const double f = 2.0 * M_PI / (double)(size - 1);
+      const int tp = (int)(size / 32);
+      std::vector<float> base((size_t)tp * 4), step(32);
+      for (int tdx = 0; tdx < tp; ++tdx)
+        for (int ee = 0; ee < 2; ++ee) {
+          base[4 * tdx + 2 * ee] = (float)std::cos(f * (2 * tdx + ee));
+          base[4 * tdx + 2 * ee + 1] = (float)std::sin(f * (2 * tdx + ee));
+        }
+      for (int q = 0; q < 16; ++q) {
+        step[2 * q] = (float)std::cos(f * 2.0 * tp * q);
+        step[2 * q + 1] = (float)std::sin(f * 2.0 * tp * q);
+      }
+      e = hipMalloc((void **)&t.wf_base, base.size() * sizeof(float));
+      if (e == hipSuccess) e = hipMemcpy(t.wf_base, base.data(), base.size() * sizeof(float), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc((void **)&t.wf_step, step.size() * sizeof(float));
+      if (e == hipSuccess) e = hipMemcpy(t.wf_step, step.data(), step.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && log2n == 14 && sizeof(T) == 4) {
       // fused createWindow (fourier.ts:14-52: f = 2 pi i / (size - 1)): angle-addition tables, built in f64
       const double f = 2.0 * M_PI / (double)(size - 1);
@@ -965,6 +996,23 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       return PDSP_OK;
     }
     bool launched = false;
+    // A window that is one of the PLAN'S OWN tables (pdsp_plan_window_f32) is known by kind: the kernels
+    // that can (whole f32 frames, N = 1024 ... 16384) then evaluate the cosine sum in registers.
+    // wmode: 0 rect, 1 table, 2 / 3 fused two- / three-term cosine sum.
+    pdsp::WinFused wf{nullptr, nullptr, 0.f, 0.f, 0.f};
+    int wmode = window ? 1 : 0;
+    if constexpr (sizeof(T) == 4) {
+      int kind = -1;  // -1: caller's table
+      for (int k = 0; k < 4; ++k)
+        if (window && window == t.win[k]) kind = k;
+      if (kind == PDSP_WIN_RECT) wmode = 0;  // createWindow("rect") is all ones
+      if (t.wf_base && g_fused_window && fast) {
+        wf.base = t.wf_base, wf.step = t.wf_step;
+        if (kind == PDSP_WIN_HANN) wmode = 2, wf.k0 = 0.5f, wf.k1 = -0.5f;
+        else if (kind == PDSP_WIN_HAMMING) wmode = 2, wf.k0 = 0.54f, wf.k1 = -0.46f;
+        else if (kind == PDSP_WIN_BLACKMAN) wmode = 3, wf.k0 = 0.42f - 0.08f, wf.k1 = -0.5f, wf.k2 = 2 * 0.08f;
+      }
+    }
     if constexpr (sizeof(T) == 4) {
       // N = 16384: two 4096-point sub-transforms per 256-thread workgroup (3 frames per CU instead of 2),
       // decimation in frequency on top (spectrum_dif16k_kernel).  A window that is one of the PLAN'S OWN
@@ -973,16 +1021,7 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       // read back, 64 KB per frame, from L2.  Any other window pointer is read as a table.
       if (fast && plan->log2n == 14 && g_split16k && t.wf_base) {
         pdsp::PeakRec *pk = reinterpret_cast<pdsp::PeakRec *>(peaks_out);
-        int kind = -1;  // -1: caller's table
-        for (int k = 0; k < 4; ++k)
-          if (window && window == t.win[k]) kind = k;
-        pdsp::WinFused wf{t.wf_base, t.wf_step, 0.f, 0.f, 0.f};
-        int mode = window ? 1 : 0;
-        if (kind == PDSP_WIN_RECT) mode = 0;  // createWindow("rect") is all ones
-        else if (kind == PDSP_WIN_HANN) mode = 2, wf.k0 = 0.5f, wf.k1 = -0.5f;
-        else if (kind == PDSP_WIN_HAMMING) mode = 2, wf.k0 = 0.54f, wf.k1 = -0.46f;
-        else if (kind == PDSP_WIN_BLACKMAN) mode = 3, wf.k0 = 0.42f - 0.08f, wf.k1 = -0.5f, wf.k2 = 2 * 0.08f;
-        if (!g_fused_window && mode >= 2) mode = 1;
+        const int mode = wmode;
 #define PDSP_DIF(W, P)                                                                                              \
   hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames,  \
                      window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch)
@@ -1004,7 +1043,8 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       }
     }
     if (!launched)
-      PDSP_HIP_TRY(launch_packed<T>(plan->log2n - 1, fast, frames, window, used, frame_stride, t.tw_half, t.twr,
+      PDSP_HIP_TRY(launch_packed<T>(plan->log2n - 1, fast, frames, wmode == 0 ? (const T *)nullptr : window,
+                                    (wmode >= 2 && plan->log2n == 14) ? 1 : wmode, wf, used, frame_stride, t.tw_half, t.twr,
                                     amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
                                     reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
   } else {

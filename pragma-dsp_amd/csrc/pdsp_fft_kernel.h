@@ -855,6 +855,16 @@ fft_tiny_staged_kernel(const LD ld, const T *__restrict__ win, T *__restrict__ o
   }
 }
 
+// Tables of a FUSED cosine-sum window (createWindow of src/xform/fourier.ts:14-52 evaluated in the kernel
+// instead of read from an N-value table): a thread's sample indices are n = (2 tid + e) + 2 TP q (+ N/2 in
+// the N = 16384 kernel), so cos(f n), f = 2 pi / (N - 1), is one angle addition from a per-thread base and a
+// per-q constant; w = k0 + c (k1 + k2 c) with (k0, k1, k2) = (a0 - a2, -a1, 2 a2)  [cos 2x = 2 c^2 - 1].
+struct WinFused {
+  const float *base;  // [TP][4]: cos, sin of f*(2 tid), cos, sin of f*(2 tid + 1)
+  const float *step;  // [16][2]: cos, sin of f*2 TP q (q < 16); N = 16384 kernel: [32][2], the second half for + N/2
+  float k0, k1, k2;
+};
+
 // Fused body of spectrum() for real frames, one frame per row, via the packed-real
 // identity: z[m] = x[2m] + i*x[2m+1] (a plain 2-wide view of the windowed frame),
 // Z = FFT_M(z) with M = N/2, then for each pair (k, M-k)
@@ -871,9 +881,11 @@ fft_tiny_staged_kernel(const LD ld, const T *__restrict__ win, T *__restrict__ o
 //         two-sided output at run time.
 //   PEAK: also reduce each frame to its SpectrumPeak (findPeak fused; `amp` may then be
 //         null = peaks-only output, 16 B per frame instead of 2*(N/2+1) B).
-template <typename T, int LOG2M, bool FAST, bool HAS_WIN, bool PEAK>
+//   WIN: 0 = rect, 1 = window table (N values), 2 / 3 = two- / three-term cosine-sum window FUSED (WinFused;
+//        FAST f32 only): no table traffic, 3-4 packed instructions per pair of samples.
+template <typename T, int LOG2M, bool FAST, int WIN, bool PEAK>
 __global__ void __launch_bounds__(kPackedWG<LOG2M>)
-spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, const long long frame_len,
+spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, const WinFused wf, const long long frame_len,
                        const long long stride, const typename vec2<T>::type *__restrict__ tw,
                        const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp,
                        T *__restrict__ ph, const int two_sided, const T s_edge, const T s_mid,
@@ -882,6 +894,13 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   using TR = FftTraits<LOG2M, LOG2E>;
   constexpr int E = TR::E, TP = TR::TP, M = TR::N;
   static_assert(LOG2M >= 5, "packed path needs TP >= 2");
+  constexpr bool HAS_WIN = WIN == 1;
+  static_assert(WIN <= 1 || (FAST && sizeof(T) == 4 && LOG2E == 4), "fused windows: whole f32 frames");
+#ifndef PDSP_PACKED_ADJ
+#define PDSP_PACKED_ADJ 1  /* 0: round-1 split (bins tid + TP*q, dword stores in two directions): A/B builds */
+#endif
+  constexpr bool kAdj = FAST && LOG2E == 4 && PDSP_PACKED_ADJ;
+  typedef T V4 __attribute__((ext_vector_type(4)));
 
   __shared__ cx<T> lds[TR::LDS_ELEMS];
 
@@ -899,10 +918,14 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   constexpr bool kRegTw = (LOG2E == 4 && TP >= 16);
   std::conditional_t<kRegTw, RegTwiddles<T, LOG2M, LOG2E>, TableTwiddles<T, LOG2M, LOG2E>> twf;
   cx<T> twk0;
+  V4 tb = V4{T(0), T(0), T(0), T(0)};  // kAdj: (W_N^(2 tid), W_N^(2 tid + 1)), the split's two bases
+  V4 wb4 = V4{T(0), T(0), T(0), T(0)};  // fused window: the thread's base (cos, sin) pairs
   cx<T> wv[(HAS_WIN && PDSP_TABLES_FIRST) ? E : 1];
   if constexpr (PDSP_TABLES_FIRST) {
     if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
-    twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
+    if constexpr (kAdj) tb = reinterpret_cast<const V4 *>(twr)[(unsigned)tid];
+    else twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
+    if constexpr (WIN >= 2) wb4 = reinterpret_cast<const V4 *>(wf.base)[(unsigned)tid];
     if constexpr (HAS_WIN) {
       const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
       static_for<E>([&](auto q) { wv[q] = (w2 + TP * q)[(unsigned)tid]; });
@@ -927,11 +950,24 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   if constexpr (PDSP_TABLES_FIRST) {
     load_order_fence();
     if constexpr (HAS_WIN) static_for<E>([&](auto q) { x[q] = x[q] * wv[q]; });
+    if constexpr (WIN >= 2) {
+      const cx<T> cb{wb4.x, wb4.z}, sb{wb4.y, wb4.w};  // (e = 0, e = 1)
+      const T k0 = wf.k0, k1 = wf.k1, k2 = wf.k2;
+      static_for<E>([&](auto qc) {
+        constexpr int q = qc;
+        const T cq = wf.step[2 * q], sq = wf.step[2 * q + 1];  // wave-uniform: scalar loads
+        const cx<T> c = cb * cq - sb * sq;                     // cos(f n), n = 2 (tid + TP q) + e
+        if constexpr (WIN == 3) x[q] = x[q] * (k0 + c * (k1 + k2 * c));
+        else x[q] = x[q] * (k0 + k1 * c);
+      });
+    }
   } else {
     // round-1 order: twiddle bases right behind the frame loads, consumed passes later
     if constexpr (kRegTw) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
     // W_N^tid: the Hermitian split needs W_N^(tid + TP*q) = twk0 * W32^q (N = 32*TP)
-    twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
+    if constexpr (kAdj) tb = reinterpret_cast<const V4 *>(twr)[(unsigned)tid];
+    else twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
+    static_assert(WIN <= 1 || PDSP_TABLES_FIRST, "fused windows are written for the tables-first order");
     if constexpr (HAS_WIN) {
       const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
       static_for<E>([&](auto q) { x[q] = x[q] * (w2 + TP * q)[(unsigned)tid]; });
@@ -953,12 +989,54 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);
   cx<T> dc_x{T(0), T(0)};
+  if constexpr (kAdj) {
+    // FAST split, round 2: a thread takes ADJACENT bins -- k0 = 2 (tid + TP q'), k1 = k0 + 1, q' < 4 -- so
+    // that its outputs are the pairs (k0, k0+1) and (M-k0-1, M-k0): 8-byte non-temporal stores (the shape
+    // that measured 6.0 vs 5.6 TB/s on the N = 16384 load / store skeleton, tools/kbench2) instead of
+    // dword stores in two directions.  W_N^(k0 + e) = twr[2 tid + e] * W_16^q'  (N = 32 TP).
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    const cx<T> tw0{tb.x, tb.y}, tw1{tb.z, tb.w};
+    static_for<4>([&](auto qc) {
+      constexpr int q = qc;
+      const int k0 = 2 * (tid + TP * q);  // even, < M/2
+      const cx<T> z0 = lrow[lds_pad(k0)], z1 = lrow[lds_pad(k0) + 1];          // k0 % 16 <= 14: same block of 16
+      const cx<T> zp0 = lrow[lds_pad((M - k0) & (M - 1))], zp1 = lrow[lds_pad(M - k0 - 1)];
+      const cx<T> w0 = mul_w32<T, 2 * q>(tw0), w1 = mul_w32<T, 2 * q>(tw1);
+      const T h0 = T(0.5) * ((k0 == 0) ? s_edge : s_mid), h1 = T(0.5) * s_mid;
+      const cx<T> e0 = (z0 + conj(zp0)) * h0, p0 = cmul(z0 - conj(zp0), w0) * h0;
+      const cx<T> e1 = (z1 + conj(zp1)) * h1, p1 = cmul(z1 - conj(zp1), w1) * h1;
+      const cx<T> xa0 = add_mul_neg_i(e0, p0), xb0 = conj(add_mul_pos_i(e0, p0));  // X[k0], X[M - k0]
+      const cx<T> xa1 = add_mul_neg_i(e1, p1), xb1 = conj(add_mul_pos_i(e1, p1));  // X[k0 + 1], X[M - k0 - 1]
+      const T ma0 = mag(xa0), mb0 = mag(xb0), ma1 = mag(xa1), mb1 = mag(xb1);
+      if constexpr (PEAK) {
+        if (k0 == 0) {
+          dc_amp = ma0;
+          dc_x = xa0;
+        } else {
+          best.consider(ma0, k0, xa0);
+        }
+        best.consider(ma1, k0 + 1, xa1);
+        best.consider(mb1, M - k0 - 1, xb1);
+        best.consider(mb0, M - k0, xb0);
+      }
+      if (store_amp) {
+        __builtin_nontemporal_store(V2{ma0, ma1}, reinterpret_cast<V2 *>(arow + (unsigned)k0));
+        __builtin_nontemporal_store(V2{mb1, mb0}, reinterpret_cast<V2 *>(arow + (unsigned)(M - k0 - 1)));
+      }
+    });
+    if (tid == 0) {  // the middle bin M/2 pairs with itself: X[M/2] = conj(Z[M/2]) scaled
+      const cx<T> xm = conj(lrow[lds_pad(M / 2)]) * s_mid;
+      const T mm = mag(xm);
+      if constexpr (PEAK) best.consider(mm, M / 2, xm);
+      if (store_amp) st_rowtail(mm, arow + (unsigned)(M / 2));
+    }
+  }
   // pairs k = tid + TP*q, q < E/2 (k < M/2); k = M/2 is one more pair for tid == 0.
   // LDS: Z[k] at pad(tid) + q*cpad(TP); Z[M-k] at pad(M - tid) - q*cpad(TP); Z[M] == Z[0].
   const cx<T> *const zlo = lrow + lds_pad(tid);
   const cx<T> *const zhi = lrow + lds_pad(M - tid);
   const cx<T> *const zhi0 = lrow + lds_pad((M - tid) & (M - 1));
-  static_for<E / 2 + 1>([&](auto qc) {
+  static_for<kAdj ? 0 : E / 2 + 1>([&](auto qc) {
     constexpr int q = qc;
     if (q < E / 2 || tid == 0) {
       const int k = tid + TP * q, k2 = M - k;
@@ -1523,13 +1601,7 @@ fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
 //   thread's sample indices are n = (2 tid + e) + 512 q (+ 8192), so cos(f n) is one angle addition from
 //   a per-thread base (one 16-byte load: cos / sin of f (2 tid + e), e = 0, 1) and a per-q constant
 //   (wave-uniform: scalar loads): 3-4 packed instructions per pair of samples and no table traffic.
-//   wcoef = (a0 - a2, -a1, 2 a2): w = k0 + c (k1 + k2 c) with c = cos(f n)  [cos 2x = 2 c^2 - 1].
-//   Values agree with the f64-built, f32-rounded table to ~2e-7 absolute.
-struct WinFused {
-  const float *base;  // [256][4]: cos, sin of f*(2 tid), cos, sin of f*(2 tid + 1)
-  const float *step;  // [32][2]: cos, sin of f*512 q (q < 16), then of f*(512 q + 8192)
-  float k0, k1, k2;
-};
+//   (WinFused above; values agree with the f64-built, f32-rounded table to ~2e-7 absolute.)
 template <typename T, int WIN, bool PEAK>
 __global__ void __launch_bounds__(256, PDSP_DIF16K_WAVES)
 spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, const WinFused wf, const long long stride,

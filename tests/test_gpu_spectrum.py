@@ -115,21 +115,24 @@ def test_spectrum_full_size_properties():
     assert float(((amp3 - 3 * amp).abs().amax(dim=1) / amp3.amax(dim=1)).max()) < 1e-6
 
 
+@pytest.mark.parametrize("n", [16384, 8192, 4096, 2048, 1024])
 @pytest.mark.parametrize("window", ["rect", "hann", "hamming", "blackman", "custom"])
-def test_dif16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, window):
-    """N = 16384 whole pair-aligned frames run on spectrum_dif16k_kernel (two 4096-point sub-transforms
-    per workgroup, decimation in frequency on top, 8-byte non-temporal stores of adjacent bins);
-    pdsp_set_split16k(0) routes the same call to spectrum_packed_kernel<13>.  A window named by kind is
-    the plan's own table, so createWindow is FUSED into the kernel (cosine sum in registers);
+def test_fast_spectrum_kernels_fused_window_vs_table_vs_oracle(pdsp, oracle_mod, window, n):
+    """Whole pair-aligned one-sided frames, the config-4 shape.  N = 16384 runs on spectrum_dif16k_kernel
+    (two 4096-point sub-transforms per workgroup, decimation in frequency on top; pdsp_set_split16k(0)
+    routes the same call to spectrum_packed_kernel<13>); N = 1024 ... 8192 on spectrum_packed_kernel's FAST
+    variant.  Both store ADJACENT bins with 8-byte non-temporal stores.  A window named by kind is the
+    plan's own table, so createWindow is FUSED into the kernel (cosine sum in registers);
     pdsp_set_fused_window(0) makes the kernel read the table instead, and a caller's own tensor
     ("custom": a Hann table plus a ripple) is always read as a table.  All against the oracle, plus guard
-    cells behind the rows (the 8-byte stores of the last row must not run over)."""
+    cells behind the rows (the 8-byte stores of the last row must not run over), fused findPeak records,
+    a zero frame and a DC frame."""
     import torch
     from pragma_dsp_amd.batch import BatchedFft
-    n, bins = 16384, 8193
+    bins, tone = n // 2 + 1, n // 21
     rng = np.random.default_rng(16)
     t = np.arange(n)
-    x = (rng.standard_normal((9, n)) * 0.3 + np.sin(2 * np.pi * 777 * t / n)[None, :]).astype(np.float32)
+    x = (rng.standard_normal((9, n)) * 0.3 + np.sin(2 * np.pi * tone * t / n)[None, :]).astype(np.float32)
     x[7] = 0.0          # zeros: exact zeros, peak 0
     x[8] = 1.0          # DC: peak stays at bin 0
     dx = torch.from_numpy(x).cuda()
@@ -142,14 +145,15 @@ def test_dif16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, window
         warg = window
     wamp, _, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, want_peak=True)
     res = {}
-    for mode in ((1, 1), (1, 0), (0, 1)):   # (dif16k kernel, fused window)
+    modes = ((1, 1), (1, 0), (0, 1)) if n == 16384 else ((1, 1), (1, 0))   # (dif16k kernel, fused window)
+    for mode in modes:
         prev = pdsp.lib.pdsp_set_split16k(mode[0])
         prevf = pdsp.lib.pdsp_set_fused_window(mode[1])
         try:
             buf = torch.full((9 * bins + 64,), -7.0, device="cuda")
             out = buf[:9 * bins].view(9, bins)
             amp, _, pki = plan.spectrum(dx, warg, "one", want_peak=True, out=out)   # peak-index array (common tail)
-            assert list(pki.cpu().numpy()[:7]) == [777] * 7 and int(pki[7]) == 0
+            assert list(pki.cpu().numpy()[:7]) == [tone] * 7 and int(pki[7]) == 0
             idx, freq, pamp, pph, _, _ = plan.spectrum_peaks(dx, warg, "one", 48000.0)
             torch.cuda.synchronize()
         finally:
@@ -162,9 +166,9 @@ def test_dif16k_kernel_matches_packed_kernel_and_oracle(pdsp, oracle_mod, window
         # DC frame: bin 0 with a rect window; with a tapering window the window's own bin 1 wins (findPeak skips DC)
         assert res[mode][1][8] == wpk[8] == (0 if window == "rect" else 1)
         assert abs(res[mode][2][8] - wamp[8, wpk[8]]) < 1e-5
-        assert list(res[mode][1][:7]) == list(wpk[:7]) == [777] * 7
+        assert list(res[mode][1][:7]) == list(wpk[:7]) == [tone] * 7
         assert np.array_equal(res[mode][0][np.arange(7), res[mode][1][:7]], res[mode][2][:7])
-    for other in ((1, 0), (0, 1)):
+    for other in modes[1:]:
         assert rel_err(res[(1, 1)][0][:7], res[other][0][:7]) <= 2e-6          # the kernels / window forms agree to rounding
         assert np.abs(((res[(1, 1)][3][:7] - res[other][3][:7]) + np.pi) % (2 * np.pi) - np.pi).max() < 1e-4
     if window in ("rect", "custom"):  # nothing to fuse: the same kernel variant runs either way
@@ -192,17 +196,18 @@ def test_plan_window_is_create_window_and_fused_window_matches_table(pdsp, oracl
             assert np.array_equal(back.cpu().numpy()[0], want)
             assert np.array_equal(w.tensor().cpu().numpy(), want)
     # fused vs table on frames that are ONE unit sample at position p: |X[k]| * N/2 = w[p] for every bin
-    n = 16384
-    plan = BatchedFft(n, "cuda:0")
-    pos = np.array([0, 1, 2, 3, 511, 512, 513, 4095, 8191, 8192, 8193, 12000, 16381, 16382, 16383])
-    x = np.zeros((len(pos), n), dtype=np.float32)
-    x[np.arange(len(pos)), pos] = 1.0
-    dx = torch.from_numpy(x).cuda()
-    for kind in ("hann", "hamming", "blackman"):
-        amp, _, _ = plan.spectrum(dx, kind, "one")
-        got = amp.cpu().numpy()[:, 5] * (n / 2)                      # any bin between DC and Nyquist
-        want = oracle_mod.create_window(kind, n)[pos]
-        assert np.abs(got - want).max() <= 5e-7, (kind, np.abs(got - want).max())
+    for n in (16384, 8192, 4096, 2048, 1024):
+        plan = BatchedFft(n, "cuda:0")
+        pos = np.unique(np.clip(np.array([0, 1, 2, 3, 63, 64, 65, 511, 512, 513, n // 4 - 1, n // 2 - 1, n // 2, n // 2 + 1,
+                                          3 * n // 4 + 13, n - 3, n - 2, n - 1]), 0, n - 1))
+        x = np.zeros((len(pos), n), dtype=np.float32)
+        x[np.arange(len(pos)), pos] = 1.0
+        dx = torch.from_numpy(x).cuda()
+        for kind in ("hann", "hamming", "blackman"):
+            amp, _, _ = plan.spectrum(dx, kind, "one")
+            got = amp.cpu().numpy()[:, 5] * (n / 2)                      # any bin between DC and Nyquist
+            want = oracle_mod.create_window(kind, n)[pos]
+            assert np.abs(got - want).max() <= 5e-7, (n, kind, np.abs(got - want).max())
 
 
 @pytest.mark.parametrize("n,batch", [(64, 1), (64, 128), (64, 131), (128, 64), (128, 77), (256, 33), (512, 16),

@@ -111,8 +111,8 @@ static int spec_main(long long frames, int rounds) {
   };
   std::vector<SV> svs;
   svs.push_back({"packed<13>", [&] {
-    hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, true, false>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
-                       dim3(TR::WG), 0, 0, x, win, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
+    hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, 1, false>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
+                       dim3(TR::WG), 0, 0, x, win, pdsp::WinFused{nullptr, nullptr, 0.f, 0.f, 0.f}, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
                        1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
   pdsp::WinFused wfz{nullptr, nullptr, 0.f, 0.f, 0.f}, wfh = wfz;
   {
