@@ -26,7 +26,8 @@ thread_local std::string g_err;
 // development switches (tools / tests): 0 routes N = 16384 spectra to spectrum_packed_kernel<13>,
 // and 32 <= N <= 256 transforms to the direct kernel instead of fft_staged_kernel
 int g_split16k = 1;
-int g_fused_window = 1;  // pdsp_set_fused_window: plan-owned cosine-sum windows evaluated in the kernel
+int g_fused_window = 1;
+int g_twopass = 1;       // pdsp_set_twopass: 2^15 <= N <= 2^18 f32 transforms in two passes (balanced factors)  // pdsp_set_fused_window: plan-owned cosine-sum windows evaluated in the kernel
 int g_split8k_f32 = 0;  // f32 N = 8192 rows on fft_split2_kernel too (A/B: pdsp_set_split16k bit 1)
 int g_staged_small = 1;
 
@@ -108,6 +109,10 @@ struct Tables {
   T2 *twa = nullptr;
   T2 *twb = nullptr;
   T2 *tw1 = nullptr;  // general four-step path (log2n1 > kMaxLog2N1): radix table of the N1-point rows
+  // two-pass path (f32, 2^15 <= N <= 2^18): N = Na * Nb, radix tables of the Na- and Nb-point transforms
+  int tp_la = 0, tp_lb = 0;
+  T2 *tp_twa = nullptr;
+  T2 *tp_twb = nullptr;
   void release() {
     if (tw12) (void)hipFree(tw12);
     tw12 = nullptr;
@@ -119,6 +124,9 @@ struct Tables {
     if (tws2) (void)hipFree(tws2);
     tws2 = nullptr;
 
+    if (tp_twa) (void)hipFree(tp_twa);
+    if (tp_twb) (void)hipFree(tp_twb);
+    tp_twa = tp_twb = nullptr;
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
     if (tw1) (void)hipFree(tw1);
@@ -462,6 +470,51 @@ int bigfft_out(const pdsp_plan *plan, long long batch, const T *b_re, const T *b
   return PDSP_OK;
 }
 
+// Two-pass transform (twopass_kernel's header): N = Na * Nb, 2^15 <= N <= 2^17, f32, 16-byte aligned planes.
+// Pass 1 writes the scratch planes, pass 2 the output: no aliasing constraint between input and output.
+template <typename T>
+int twopass_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out,
+                    T scale, T *s_re, T *s_im, hipStream_t s) {
+  const Tables<T> &t = tables<T>(plan);
+  const int na = 1 << t.tp_la, nb = 1 << t.tp_lb;
+  // 32 columns / rows per workgroup: 128-byte segments on the strided side (measured at N = 65536:
+  // 16-wide tiles 1.6-1.8, 32-wide 2.6-2.7, 64-wide -- one workgroup per CU -- 2.1 TB/s algorithmic);
+  // 512-point factors hold 16 per workgroup (70 KB of LDS)
+  const int tile_a = t.tp_la == 9 ? 16 : 32, tile_b = t.tp_lb == 9 ? 16 : 32;
+  const long long g1 = batch * (nb / tile_a), g2 = batch * (na / tile_b);
+  if (g1 > 0x7fffffffLL || g2 > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
+  const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
+  const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
+#define PDSP_TP_COLS(L, TILE)                                                                                        \
+  do {                                                                                                               \
+    if (im_in)                                                                                                       \
+      hipLaunchKernelGGL((pdsp::twopass_kernel<T, L, TILE, true, false>), dim3((unsigned)g1), dim3(256), 0, s, re_in, \
+                         im_in, s_re, s_im, t.tp_twa, twa, twb, nb, T(1), batch);                                    \
+    else                                                                                                             \
+      hipLaunchKernelGGL((pdsp::twopass_kernel<T, L, TILE, true, true>), dim3((unsigned)g1), dim3(256), 0, s, re_in,  \
+                         im_in, s_re, s_im, t.tp_twa, twa, twb, nb, T(1), batch);                                    \
+  } while (0)
+  switch (t.tp_la) {
+    case 7: PDSP_TP_COLS(7, 32); break;
+    case 8: PDSP_TP_COLS(8, 32); break;
+    case 9: PDSP_TP_COLS(9, 16); break;
+    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported two-pass split");
+  }
+#undef PDSP_TP_COLS
+  PDSP_HIP_TRY(hipGetLastError());
+#define PDSP_TP_ROWS(L, TILE)                                                                                       \
+  hipLaunchKernelGGL((pdsp::twopass_kernel<T, L, TILE, false>), dim3((unsigned)g2), dim3(256), 0, s, (const T *)s_re, \
+                     (const T *)s_im, re_out, im_out, t.tp_twb, twa, twb, na, scale, batch)
+  switch (t.tp_lb) {
+    case 8: PDSP_TP_ROWS(8, 32); break;
+    case 9: PDSP_TP_ROWS(9, 16); break;
+    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported two-pass split");
+  }
+#undef PDSP_TP_ROWS
+  PDSP_HIP_TRY(hipGetLastError());
+  return PDSP_OK;
+}
+
 template <typename T>
 int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out, T scale,
                 hipStream_t s) {
@@ -490,6 +543,13 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
     StreamScratch mem(s);
     PDSP_HIP_TRY(mem.alloc(2 * plane * sizeof(T)));
     T *const scratch = (T *)mem.p;
+    if constexpr (sizeof(T) == 4) {
+      // two passes with balanced factors where the tables exist (2^15 <= N <= 2^17) and every plane is
+      // 16-byte aligned; pdsp_set_twopass(0) keeps the three-pass fused-columns form (A/B tests)
+      if (t.tp_twa && g_twopass &&
+          (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0)
+        return twopass_complex<T>(plan, batch, re_in, im_in, re_out, im_out, scale, scratch, scratch + plane, s);
+    }
     int rc = fourstep_ab<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, scratch, scratch + plane, s);
     if (!rc) rc = fourstep_c<T, 0>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
     return rc;
@@ -812,6 +872,16 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
       if (e == hipSuccess) e = hipMemcpy(t.twa, a.data(), a.size() * sizeof(T2), hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMalloc((void **)&t.twb, b.size() * sizeof(T2));
       if (e == hipSuccess) e = hipMemcpy(t.twb, b.data(), b.size() * sizeof(T2), hipMemcpyHostToDevice);
+      // two-pass path, balanced factors: 2^15 ... 2^17 (at 2^18 = 512 x 512 both passes move 64-byte
+      // segments and the three-pass form measures the same, 1.8 TB/s: it keeps that size)
+      if (e == hipSuccess && sizeof(T) == 4 && log2n >= 15 && log2n <= 17) {
+        t.tp_la = log2n / 2, t.tp_lb = log2n - t.tp_la;
+        const std::vector<T2> ta = build_twiddles<T2>(t.tp_la), tb = build_twiddles<T2>(t.tp_lb);
+        e = hipMalloc((void **)&t.tp_twa, ta.size() * sizeof(T2));
+        if (e == hipSuccess) e = hipMemcpy(t.tp_twa, ta.data(), ta.size() * sizeof(T2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.tp_twb, tb.size() * sizeof(T2));
+        if (e == hipSuccess) e = hipMemcpy(t.tp_twb, tb.data(), tb.size() * sizeof(T2), hipMemcpyHostToDevice);
+      }
       if (e == hipSuccess && t.log2n1 > pdsp::kMaxLog2N1) {
         const std::vector<T2> t1 = build_twiddles<T2>(t.log2n1);
         e = hipMalloc((void **)&t.tw1, t1.size() * sizeof(T2));
@@ -1234,6 +1304,12 @@ int pdsp_set_split16k(int enabled) {
   const int prev = g_split16k;
   g_split16k = enabled ? 1 : 0;
   g_split8k_f32 = (enabled & 2) ? 1 : 0;
+  return prev;
+}
+
+int pdsp_set_twopass(int enabled) {
+  const int prev = g_twopass;
+  g_twopass = enabled ? 1 : 0;
   return prev;
 }
 

@@ -1775,6 +1775,112 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   }
 }
 
+// ---- two-pass path for 2^15 <= N <= 2^17 (f32) -------------------------------------------------
+// N = Na * Nb with BALANCED factors (128..512 each) instead of N1 * 16384: input index n = n1*Nb + n2,
+// output index k = k1 + Na*k2,
+//   X[k1 + Na k2] = sum_n2 W_Nb^(n2 k2) * [ W_N^(n2 k1) * sum_n1 x[n1 Nb + n2] W_Na^(n1 k1) ].
+//   pass 1 (COLS): the Na-point transforms down the columns, times W_N^(n2 k1), written back in place of
+//                  the matrix [k1][n2] (scratch);
+//   pass 2 (ROWS): the Nb-point transforms along the rows k1, written TRANSPOSED to k1 + Na*k2.
+// Two passes over HBM (32 B per sample of traffic for 16 algorithmic) where the fused-columns four-step
+// of round 1 made three (N1-point columns / 16384-point rows / transposing copy).  A 256-thread workgroup
+// owns TILE = 32 (16 for 512-point transforms) columns / rows at a time: the strided side of each pass
+// moves TILE consecutive floats per matrix row -- 128-byte (64-byte) segments, 16 bytes per lane -- and the
+// transposition happens in LDS, where the tile's transforms also run (fft_passes on TILE LDS rows, 256/TP
+// rows per round).  LDS rows are LROW + 2 elements apart: (L + L/16) is a multiple of 8 for L >= 128, and
+// four rows must not land on the same banks when a lane quad writes one element to each of four rows.
+//   tw = radix table of the L-point transform; W_N^m = twa[m >> 9] * twb[m & 511].
+//   COLS: in = [L rows][other = Nb] (strided tile), out = same layout.   in_im may be null (real input).
+//   ROWS: in = [TILE rows of L contiguous points], out[p * other + row], other = Na; times `scale`.
+template <typename T, int LOG2L, int TILE, bool COLS, bool REAL_IN = false>
+__global__ void __launch_bounds__(256)
+twopass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
+               const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
+               const cx<T> *__restrict__ twb, const int other, const T scale, const long long batch) {
+  using TR = FftTraits<LOG2L>;
+  constexpr int L = TR::N, E = TR::E, TP = TR::TP, RPR = 256 / TP, ROUNDS = TILE / RPR;
+  static_assert(LOG2L >= 7 && LOG2L <= 9 && TILE % RPR == 0 && TILE % 4 == 0, "tile of whole rounds");
+  constexpr int LROWX = TR::LROW + 2;
+  constexpr int TS = TILE / 4, SPI = 256 / TS;  // threads per tile segment, segments per wave of accesses
+  static_assert(L % SPI == 0, "whole accesses");
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[TILE * LROWX];
+
+  const int t = (int)threadIdx.x;
+  const int tiles = other / TILE;
+  const long long b = (long long)blockIdx.x / tiles;
+  const int t0 = (int)((long long)blockIdx.x % tiles) * TILE;
+  if (b >= batch) return;
+  const size_t nn = (size_t)L * (size_t)other;  // N
+  const size_t base = (size_t)b * nn;
+  const int seg = t / TS, j4 = (t % TS) * 4;
+
+  if constexpr (COLS) {
+    // strided tile in: element (p, j) = in[p*other + t0 + j] -> LDS row j, position p
+    static_for<L / SPI>([&](auto ic) {
+      const int p = seg + SPI * ic;
+      const size_t g = base + (size_t)p * (size_t)other + (size_t)(t0 + j4);
+      const V4 r = ld_stream(reinterpret_cast<const V4 *>(in_re + g));
+      V4 m = V4{T(0), T(0), T(0), T(0)};
+      if constexpr (!REAL_IN) m = ld_stream(reinterpret_cast<const V4 *>(in_im + g));
+      cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
+      d[0 * LROWX] = cx<T>{r.x, m.x};
+      d[1 * LROWX] = cx<T>{r.y, m.y};
+      d[2 * LROWX] = cx<T>{r.z, m.z};
+      d[3 * LROWX] = cx<T>{r.w, m.w};
+    });
+  } else {
+    // TILE whole rows, one contiguous chunk per plane
+    const size_t cbase = base + (size_t)t0 * L;
+    static_for<TILE * L / 4 / 256>([&](auto ic) {
+      const int e = 4 * (t + 256 * ic);
+      const V4 r = ld_stream(reinterpret_cast<const V4 *>(in_re + cbase + e));
+      const V4 m = ld_stream(reinterpret_cast<const V4 *>(in_im + cbase + e));
+      cx<T> *const d = lds + (e / L) * LROWX + lds_pad(e % L);  // 4 points never straddle a 16-block
+      d[0] = cx<T>{r.x, m.x};
+      d[1] = cx<T>{r.y, m.y};
+      d[2] = cx<T>{r.z, m.z};
+      d[3] = cx<T>{r.w, m.w};
+    });
+  }
+  __syncthreads();
+
+  const int tid = t % TP, rloc = t / TP;
+  RegTwiddles<T, LOG2L> twf;
+  twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  static_for<ROUNDS>([&](auto rc) {
+    cx<T> *const lrow = lds + (rc * RPR + rloc) * LROWX;
+    cx<T> x[E];
+    static_for<E>([&](auto q) { x[q] = lrow[lds_pad(tid + TP * q)]; });
+    __syncthreads();  // the first pass scatters into the same rows
+    fft_passes<T, LOG2L, true>(x, lrow, twf, tid);  // natural order in LDS
+  });
+  __syncthreads();
+
+  // strided tile out: element (p, j) -> out[p*other + t0 + j]
+  static_for<L / SPI>([&](auto ic) {
+    const int p = seg + SPI * ic;
+    const cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
+    cx<T> v[4] = {d[0 * LROWX], d[1 * LROWX], d[2 * LROWX], d[3 * LROWX]};
+    if constexpr (COLS) {
+      // W_N^((t0 + j4 + j) p), j = 0..3: one two-level lookup for j = 0, then steps of W_N^p (p < 512: twb[p])
+      const unsigned m = (unsigned)(t0 + j4) * (unsigned)p;  // < N <= 2^18
+      cx<T> w = cmul(twa[m >> 9], twb[m & 511]);
+      const cx<T> ws = twb[p];
+      v[0] = cmul(v[0], w);
+      static_for<3>([&](auto jc) {
+        w = cmul(w, ws);
+        v[jc + 1] = cmul(v[jc + 1], w);
+      });
+    } else {
+      static_for<4>([&](auto jc) { v[jc] = v[jc] * scale; });
+    }
+    const size_t g = base + (size_t)p * (size_t)other + (size_t)(t0 + j4);
+    st_stream(V4{v[0].x, v[1].x, v[2].x, v[3].x}, reinterpret_cast<V4 *>(out_re + g));
+    st_stream(V4{v[0].y, v[1].y, v[2].y, v[3].y}, reinterpret_cast<V4 *>(out_im + g));
+  });
+}
+
 // ---- general four-step path: N = N1 * N2 with 32 <= N1 <= N2 = the largest single-pass size ---
 // Input index n = n1*N2 + n2, output index k = k1 + N1*k2; both factors run on the row kernels,
 // so the data is transposed between them (Bailey's four-step):

@@ -125,3 +125,44 @@ def test_general_four_step_n_2_24(oracle_mod):
         bre, bim = plan.inverse(ore, oim)
         assert rel_err(bre.cpu().numpy(), re) <= tol and rel_err(bim.cpu().numpy(), im) <= tol
         del plan, dre, dim, ore, oim, bre, bim
+
+
+@pytest.mark.parametrize("log2n", [15, 16, 17, 18])
+def test_twopass_vs_threepass_vs_oracle(pdsp, oracle_mod, log2n):
+    """2^15 <= N <= 2^17 in f32 (2^18 stays on the three-pass form either way): twopass_kernel (N = Na * Nb, balanced factors, two passes over HBM) against
+    the three-pass fused-columns four-step (pdsp_set_twopass(0)) and the oracle: complex, real input,
+    inverse, an in-place call (output planes = input planes) and a batch that is not a multiple of anything."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n, batch = 1 << log2n, 5
+    rng = np.random.default_rng(100 + log2n)
+    re = rng.standard_normal((batch, n)).astype(np.float32)
+    im = rng.standard_normal((batch, n)).astype(np.float32)
+    re[1] = 0.0
+    im[1] = 0.0
+    re[1, 3] = 1.0                                       # an impulse row: |X| = 1 everywhere
+    plan = BatchedFft(n, "cuda:0")
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    want = wre + 1j * wim
+    rre_w, rim_w = oracle_mod.Plan(n).forward(re)
+    res = {}
+    for mode in (1, 0):
+        prev = pdsp.lib.pdsp_set_twopass(mode)
+        try:
+            dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+            ore, oim = plan.forward(dre, dim)
+            got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
+            assert rel_err(got, want) <= 1e-5
+            assert np.abs(np.abs(got[1]) - 1.0).max() < 1e-5
+            bre, bim = plan.inverse(ore, oim)
+            assert np.abs(bre.cpu().numpy() - re).max() <= 1e-5 * np.abs(re).max() * 4
+            assert np.abs(bim.cpu().numpy() - im).max() <= 1e-5 * np.abs(im).max() * 4
+            rre, rim = plan.forward(dre)                  # Radix2Fft.forward: real input
+            assert rel_err(rre.cpu().numpy().astype(np.float64) + 1j * rim.cpu().numpy(), rre_w + 1j * rim_w) <= 1e-5
+            plan.forward(dre, dim, out=(dre, dim))        # in place
+            torch.cuda.synchronize()
+            assert rel_err(dre.cpu().numpy().astype(np.float64) + 1j * dim.cpu().numpy(), want) <= 1e-5
+        finally:
+            pdsp.lib.pdsp_set_twopass(prev)
+        res[mode] = got
+    assert rel_err(res[1], res[0]) <= 2e-6

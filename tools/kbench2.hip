@@ -233,6 +233,45 @@ __global__ void __launch_bounds__(256) read_kernel(const V4 *__restrict__ in, V4
   if (acc.x == 12345.678f) out[0] = acc;
 }
 
+// I/O skeleton of the planar C2C kernel at N = 4096: one 256-thread workgroup per row, both planes in,
+// both planes out, W floats per lane per access (W = 1: the shipped dword shape tid + 256q).
+template <int W, bool NT_ST>
+__global__ void __launch_bounds__(256) c2c_skel_kernel(const float *__restrict__ re, const float *__restrict__ im,
+                                                       float *__restrict__ ore, float *__restrict__ oim) {
+  typedef float VW __attribute__((ext_vector_type(W)));
+  constexpr int PER = 16 / W;  // accesses per plane per thread
+  const size_t base = (size_t)blockIdx.x * 4096;
+  const VW *r = reinterpret_cast<const VW *>(re + base), *i = reinterpret_cast<const VW *>(im + base);
+  VW *orr = reinterpret_cast<VW *>(ore + base), *oi = reinterpret_cast<VW *>(oim + base);
+  VW a[PER], b[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    a[q] = __builtin_nontemporal_load(r + 256 * q + threadIdx.x);
+    b[q] = __builtin_nontemporal_load(i + 256 * q + threadIdx.x);
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const VW x = a[q] + b[q], y = a[q] - b[q];
+    if (NT_ST) {
+      __builtin_nontemporal_store(x, orr + 256 * q + threadIdx.x);
+      __builtin_nontemporal_store(y, oi + 256 * q + threadIdx.x);
+    } else {
+      orr[256 * q + threadIdx.x] = x;
+      oi[256 * q + threadIdx.x] = y;
+    }
+  }
+}
+// one element per thread (tiny workgroups), 16-byte accesses: the 1:1 ceiling of the part
+template <bool NT_ST>
+__global__ void __launch_bounds__(256) copy11_kernel(const V4 *__restrict__ in, V4 *__restrict__ out, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    const V4 v = __builtin_nontemporal_load(in + i);
+    if (NT_ST) __builtin_nontemporal_store(v, out + i);
+    else out[i] = v;
+  }
+}
+
 int main(int argc, char **argv) {
   const long long frames = argc > 1 ? atoll(argv[1]) : 16384;
   const int rounds = argc > 2 ? atoi(argv[2]) : 10;
@@ -281,6 +320,35 @@ int main(int argc, char **argv) {
   vs.push_back({"mix 2:1 x4, nt st, one pass (grid = n4/256)", [&] { hipLaunchKernelGGL(mix21_kernel<true>, dim3((unsigned)(n4 / 256)), dim3(256), 0, 0, (const V4 *)x, (V4 *)amp, n4); }, mb, {}});
   vs.push_back({"read-only x4 grid-stride 2048 WGs", [&] { hipLaunchKernelGGL(read_kernel, dim3(2048), dim3(256), 0, 0, (const V4 *)x, (V4 *)amp, 2 * n4); }, 16.0 * 2 * n4, {}});
 
+  if (argc > 3 && std::string(argv[3]) == "c2c") {
+    // planar C2C skeletons: rows = frames * 4 rows of 4096 points in each of two input planes
+    vs.clear();
+    const long long rows = frames * 2;  // x holds frames*16384 floats = two planes of rows*4096
+    float *ore = amp, *oim;
+    CK(hipMalloc(&oim, (size_t)rows * 4096 * 4));
+    float *ore2;
+    CK(hipMalloc(&ore2, (size_t)rows * 4096 * 4));
+    ore = ore2;
+    const float *re = x, *im = x + (size_t)rows * 4096;
+    const double cb = 16.0 * rows * 4096;
+#define C2(NAME, ...) vs.push_back({NAME, [=] { __VA_ARGS__; }, cb, {}})  /* by value: these locals end with the block */
+    C2("c2c skel dword ld, dword nt st (shipped shape)", hipLaunchKernelGGL((c2c_skel_kernel<1, true>), dim3(rows), dim3(256), 0, 0, re, im, ore, oim));
+    C2("c2c skel x2 ld, x2 nt st", hipLaunchKernelGGL((c2c_skel_kernel<2, true>), dim3(rows), dim3(256), 0, 0, re, im, ore, oim));
+    C2("c2c skel x4 ld, x4 nt st", hipLaunchKernelGGL((c2c_skel_kernel<4, true>), dim3(rows), dim3(256), 0, 0, re, im, ore, oim));
+    C2("c2c skel x2 ld, x2 plain st", hipLaunchKernelGGL((c2c_skel_kernel<2, false>), dim3(rows), dim3(256), 0, 0, re, im, ore, oim));
+    C2("c2c skel dword ld, dword plain st", hipLaunchKernelGGL((c2c_skel_kernel<1, false>), dim3(rows), dim3(256), 0, 0, re, im, ore, oim));
+    // the shipped shape with occupancy capped by a dynamic LDS allocation (bytes in flight per CU)
+    for (int wgs : {1, 2, 3, 4, 6}) {
+      const int ldsb = 160 * 1024 / wgs - 512;
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&c2c_skel_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      static std::string names[8];
+      names[wgs] = "c2c skel dword/dword nt, " + std::to_string(wgs) + " workgroup(s) per CU (LDS cap)";
+      vs.push_back({names[wgs], [=] { hipLaunchKernelGGL((c2c_skel_kernel<1, true>), dim3(rows), dim3(256), ldsb, 0, re, im, ore, oim); }, cb, {}});
+    }
+    const size_t c4 = (size_t)rows * 4096 / 4;
+    C2("copy 1:1 x4 one element per thread, nt st (2 launches)", hipLaunchKernelGGL(copy11_kernel<true>, dim3((unsigned)(c4 / 256)), dim3(256), 0, 0, (const V4 *)re, (V4 *)ore, c4); hipLaunchKernelGGL(copy11_kernel<true>, dim3((unsigned)(c4 / 256)), dim3(256), 0, 0, (const V4 *)im, (V4 *)oim, c4));
+    C2("copy 1:1 x4 one element per thread, plain st", hipLaunchKernelGGL(copy11_kernel<false>, dim3((unsigned)(c4 / 256)), dim3(256), 0, 0, (const V4 *)re, (V4 *)ore, c4); hipLaunchKernelGGL(copy11_kernel<false>, dim3((unsigned)(c4 / 256)), dim3(256), 0, 0, (const V4 *)im, (V4 *)oim, c4));
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
