@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,hop", [(8, 1), (64, 16), (256, 64), (256, 100), (1024, 256), (1024, 333), (4096, 1024),
-                                   (16384, 4096), (16384, 4097), (65536, 16384)])
+                                   (4096, 1026),
+                                   (8192, 2050), (16384, 4096), (16384, 4097), (16384, 4098), (65536, 16384)])
 @pytest.mark.parametrize("window", ["rect", "hann"])
 def test_stft_matches_materialised_frames(oracle_mod, n, hop, window):
     import torch
