@@ -111,10 +111,10 @@ PDSP_API int pdsp_set_staged_small(int enabled);
  * as a table like any caller-supplied window.  A/B switch for the parity tests; returns the
  * previous value. */
 PDSP_API int pdsp_set_fused_window(int enabled);
-/* 1 (default): f32 transforms of 2^15 <= N <= 2^17 on 16-byte aligned planes run in TWO passes over
- * HBM (N = Na * Nb with balanced factors, twopass_kernel); 0: the three-pass fused-columns four-step
- * (N1 <= 16 columns, 16384-point rows, transposing copy).  Same results within rounding; A/B switch,
- * returns the previous value. */
+/* 1 (default): f32 transforms of 2^15 <= N <= 2^27 on 16-byte aligned planes run as tile passes over
+ * balanced factors of 64 ... 512 points (tile_pass_kernel): TWO passes over HBM up to 2^17, THREE above;
+ * 0: round 1's four-step forms (N1 <= 16 columns, 16384-point rows, transposing copy: three passes up to
+ * 2^18, five above).  Same results within rounding; A/B switch, returns the previous value. */
 PDSP_API int pdsp_set_twopass(int enabled);
 
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).

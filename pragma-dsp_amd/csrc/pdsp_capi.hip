@@ -109,10 +109,11 @@ struct Tables {
   T2 *twa = nullptr;
   T2 *twb = nullptr;
   T2 *tw1 = nullptr;  // general four-step path (log2n1 > kMaxLog2N1): radix table of the N1-point rows
-  // two-pass path (f32, 2^15 <= N <= 2^18): N = Na * Nb, radix tables of the Na- and Nb-point transforms
-  int tp_la = 0, tp_lb = 0;
-  T2 *tp_twa = nullptr;
-  T2 *tp_twb = nullptr;
+  // tile passes (f32): N = product of tp_np balanced factors 2^tp_l[i] (two for 2^15..2^17, three for
+  // 2^18..2^27), radix table of each factor's transform
+  int tp_np = 0;
+  int tp_l[3] = {0, 0, 0};
+  T2 *tp_tw[3] = {nullptr, nullptr, nullptr};
   void release() {
     if (tw12) (void)hipFree(tw12);
     tw12 = nullptr;
@@ -124,9 +125,11 @@ struct Tables {
     if (tws2) (void)hipFree(tws2);
     tws2 = nullptr;
 
-    if (tp_twa) (void)hipFree(tp_twa);
-    if (tp_twb) (void)hipFree(tp_twb);
-    tp_twa = tp_twb = nullptr;
+    for (T2 *&q : tp_tw) {
+      if (q) (void)hipFree(q);
+      q = nullptr;
+    }
+    tp_np = 0;
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
     if (tw1) (void)hipFree(tw1);
@@ -470,49 +473,65 @@ int bigfft_out(const pdsp_plan *plan, long long batch, const T *b_re, const T *b
   return PDSP_OK;
 }
 
-// Two-pass transform (twopass_kernel's header): N = Na * Nb, 2^15 <= N <= 2^17, f32, 16-byte aligned planes.
-// Pass 1 writes the scratch planes, pass 2 the output: no aliasing constraint between input and output.
-template <typename T>
-int twopass_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out,
-                    T scale, T *s_re, T *s_im, hipStream_t s) {
-  const Tables<T> &t = tables<T>(plan);
-  const int na = 1 << t.tp_la, nb = 1 << t.tp_lb;
-  // 32 columns / rows per workgroup: 128-byte segments on the strided side (measured at N = 65536:
-  // 16-wide tiles 1.6-1.8, 32-wide 2.6-2.7, 64-wide -- one workgroup per CU -- 2.1 TB/s algorithmic);
-  // 512-point factors hold 16 per workgroup (70 KB of LDS)
-  const int tile_a = t.tp_la == 9 ? 16 : 32, tile_b = t.tp_lb == 9 ? 16 : 32;
-  const long long g1 = batch * (nb / tile_a), g2 = batch * (na / tile_b);
-  if (g1 > 0x7fffffffLL || g2 > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
+// One launch of tile_pass_kernel for a factor of 2^l points (tile width by factor: 64 / 32 / 32 / 16).
+template <typename T, bool COLS>
+int tile_pass(int l, bool real_in, const T *in_re, const T *in_im, T *out_re, T *out_im,
+              const typename pdsp::vec2<T>::type *tw, const Tables<T> &t, pdsp::TileGeom g, T scale, long long batch,
+              hipStream_t s) {
+  const long long blocks = batch * g.nblk * g.tiles;
+  if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
   const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
   const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
-#define PDSP_TP_COLS(L, TILE)                                                                                        \
-  do {                                                                                                               \
-    if (im_in)                                                                                                       \
-      hipLaunchKernelGGL((pdsp::twopass_kernel<T, L, TILE, true, false>), dim3((unsigned)g1), dim3(256), 0, s, re_in, \
-                         im_in, s_re, s_im, t.tp_twa, twa, twb, nb, T(1), batch);                                    \
-    else                                                                                                             \
-      hipLaunchKernelGGL((pdsp::twopass_kernel<T, L, TILE, true, true>), dim3((unsigned)g1), dim3(256), 0, s, re_in,  \
-                         im_in, s_re, s_im, t.tp_twa, twa, twb, nb, T(1), batch);                                    \
+#define PDSP_TILE(L, TILE)                                                                                            \
+  do {                                                                                                                \
+    if (COLS && real_in)                                                                                              \
+      hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, COLS>), dim3((unsigned)blocks), dim3(256), 0, s,    \
+                         in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch);                                \
+    else                                                                                                              \
+      hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, false>), dim3((unsigned)blocks), dim3(256), 0, s,   \
+                         in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch);                                \
   } while (0)
-  switch (t.tp_la) {
-    case 7: PDSP_TP_COLS(7, 32); break;
-    case 8: PDSP_TP_COLS(8, 32); break;
-    case 9: PDSP_TP_COLS(9, 16); break;
-    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported two-pass split");
+  switch (l) {
+    case 6: PDSP_TILE(6, 64); break;
+    case 7: PDSP_TILE(7, 32); break;
+    case 8: PDSP_TILE(8, 32); break;
+    case 9: PDSP_TILE(9, 16); break;
+    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported tile-pass factor 2^%d", l);
   }
-#undef PDSP_TP_COLS
-  PDSP_HIP_TRY(hipGetLastError());
-#define PDSP_TP_ROWS(L, TILE)                                                                                       \
-  hipLaunchKernelGGL((pdsp::twopass_kernel<T, L, TILE, false>), dim3((unsigned)g2), dim3(256), 0, s, (const T *)s_re, \
-                     (const T *)s_im, re_out, im_out, t.tp_twb, twa, twb, na, scale, batch)
-  switch (t.tp_lb) {
-    case 8: PDSP_TP_ROWS(8, 32); break;
-    case 9: PDSP_TP_ROWS(9, 16); break;
-    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported two-pass split");
-  }
-#undef PDSP_TP_ROWS
+#undef PDSP_TILE
   PDSP_HIP_TRY(hipGetLastError());
   return PDSP_OK;
+}
+constexpr int tile_width(int l) { return l == 6 ? 64 : (l == 9 ? 16 : 32); }
+
+// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27 (not 2^18), f32, 16-byte aligned
+// planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
+// pass reads one pair and writes another, so input and output may alias each other.
+template <typename T>
+int tilepass_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out,
+                     T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s) {
+  const Tables<T> &t = tables<T>(plan);
+  const long long n = plan->n;
+  if (t.tp_np == 2) {
+    const long long a = 1LL << t.tp_l[0], b = 1LL << t.tp_l[1];
+    pdsp::TileGeom g1{n, 1, (int)(b / tile_width(t.tp_l[0])), 0, 0, b, b, 1u};
+    if (int rc = tile_pass<T, true>(t.tp_l[0], im_in == nullptr, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
+      return rc;
+    pdsp::TileGeom g2{n, 1, (int)(a / tile_width(t.tp_l[1])), 0, 0, 0, a, 1u};
+    return tile_pass<T, false>(t.tp_l[1], false, (const T *)s1_re, (const T *)s1_im, re_out, im_out, t.tp_tw[1], t, g2, scale,
+                               batch, s);
+  }
+  const long long a = 1LL << t.tp_l[0], b = 1LL << t.tp_l[1], c = 1LL << t.tp_l[2];
+  pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(t.tp_l[0])), 0, 0, b * c, b * c, 1u};
+  if (int rc = tile_pass<T, true>(t.tp_l[0], im_in == nullptr, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
+    return rc;
+  pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(t.tp_l[1])), b * c, c, c, a * c, (unsigned)a};
+  if (int rc = tile_pass<T, true>(t.tp_l[1], false, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, t.tp_tw[1], t, g2, T(1),
+                                  batch, s))
+    return rc;
+  pdsp::TileGeom g3{n, 1, (int)(a * b / tile_width(t.tp_l[2])), 0, 0, 0, a * b, 1u};
+  return tile_pass<T, false>(t.tp_l[2], false, (const T *)s2_re, (const T *)s2_im, re_out, im_out, t.tp_tw[2], t, g3, scale,
+                             batch, s);
 }
 
 template <typename T>
@@ -527,6 +546,25 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
                 pdsp_max_size((int)sizeof(T)));
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
+  if constexpr (sizeof(T) == 4) {
+    // tile passes with balanced factors (two for 2^15..2^17, three for 2^19..2^27) where the tables exist and
+    // every plane is 16-byte aligned; pdsp_set_twopass(0) keeps round 1's four-step forms (A/B tests)
+    if (t.tp_np && g_twopass &&
+        (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {
+      const size_t plane = (size_t)batch * (size_t)plan->n;
+      const bool aliased = re_out == re_in || re_out == im_in || im_out == re_in || im_out == im_in;
+      // two passes: one scratch pair.  Three passes: the output planes double as the first scratch pair
+      // unless they alias the input.
+      const int pairs = t.tp_np == 2 ? 1 : (aliased ? 2 : 1);
+      StreamScratch mem(s);
+      PDSP_HIP_TRY(mem.alloc((size_t)pairs * 2 * plane * sizeof(T)));
+      T *const sc = (T *)mem.p;
+      if (t.tp_np == 2)
+        return tilepass_complex<T>(plan, batch, re_in, im_in, re_out, im_out, scale, sc, sc + plane, nullptr, nullptr, s);
+      T *s1_re = aliased ? sc + 2 * plane : re_out, *s1_im = aliased ? sc + 3 * plane : im_out;
+      return tilepass_complex<T>(plan, batch, re_in, im_in, re_out, im_out, scale, s1_re, s1_im, sc, sc + plane, s);
+    }
+  }
   if (t.log2n1 > pdsp::kMaxLog2N1) {  // general four-step: the output planes double as the first scratch pair
     const size_t plane = (size_t)batch * (size_t)plan->n;
     const bool aliased = re_out == re_in || re_out == im_in || im_out == re_in || im_out == im_in;
@@ -543,13 +581,6 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
     StreamScratch mem(s);
     PDSP_HIP_TRY(mem.alloc(2 * plane * sizeof(T)));
     T *const scratch = (T *)mem.p;
-    if constexpr (sizeof(T) == 4) {
-      // two passes with balanced factors where the tables exist (2^15 <= N <= 2^17) and every plane is
-      // 16-byte aligned; pdsp_set_twopass(0) keeps the three-pass fused-columns form (A/B tests)
-      if (t.tp_twa && g_twopass &&
-          (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0)
-        return twopass_complex<T>(plan, batch, re_in, im_in, re_out, im_out, scale, scratch, scratch + plane, s);
-    }
     int rc = fourstep_ab<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, scratch, scratch + plane, s);
     if (!rc) rc = fourstep_c<T, 0>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
     return rc;
@@ -872,15 +903,21 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
       if (e == hipSuccess) e = hipMemcpy(t.twa, a.data(), a.size() * sizeof(T2), hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMalloc((void **)&t.twb, b.size() * sizeof(T2));
       if (e == hipSuccess) e = hipMemcpy(t.twb, b.data(), b.size() * sizeof(T2), hipMemcpyHostToDevice);
-      // two-pass path, balanced factors: 2^15 ... 2^17 (at 2^18 = 512 x 512 both passes move 64-byte
-      // segments and the three-pass form measures the same, 1.8 TB/s: it keeps that size)
-      if (e == hipSuccess && sizeof(T) == 4 && log2n >= 15 && log2n <= 17) {
-        t.tp_la = log2n / 2, t.tp_lb = log2n - t.tp_la;
-        const std::vector<T2> ta = build_twiddles<T2>(t.tp_la), tb = build_twiddles<T2>(t.tp_lb);
-        e = hipMalloc((void **)&t.tp_twa, ta.size() * sizeof(T2));
-        if (e == hipSuccess) e = hipMemcpy(t.tp_twa, ta.data(), ta.size() * sizeof(T2), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.tp_twb, tb.size() * sizeof(T2));
-        if (e == hipSuccess) e = hipMemcpy(t.tp_twb, tb.data(), tb.size() * sizeof(T2), hipMemcpyHostToDevice);
+      // tile passes, balanced factors (tile_pass_kernel's header), ascending so that the widest tiles
+      // serve the passes with two strided streams
+      if (e == hipSuccess && sizeof(T) == 4 && log2n >= 15 && log2n <= 27) {
+        if (log2n <= 17) {
+          t.tp_np = 2;
+          t.tp_l[0] = log2n / 2, t.tp_l[1] = log2n - t.tp_l[0];
+        } else {
+          t.tp_np = 3;
+          t.tp_l[0] = log2n / 3, t.tp_l[1] = (log2n - t.tp_l[0]) / 2, t.tp_l[2] = log2n - t.tp_l[0] - t.tp_l[1];
+        }
+        for (int i = 0; i < t.tp_np && e == hipSuccess; ++i) {
+          const std::vector<T2> tf = build_twiddles<T2>(t.tp_l[i]);
+          e = hipMalloc((void **)&t.tp_tw[i], tf.size() * sizeof(T2));
+          if (e == hipSuccess) e = hipMemcpy(t.tp_tw[i], tf.data(), tf.size() * sizeof(T2), hipMemcpyHostToDevice);
+        }
       }
       if (e == hipSuccess && t.log2n1 > pdsp::kMaxLog2N1) {
         const std::vector<T2> t1 = build_twiddles<T2>(t.log2n1);

@@ -1775,54 +1775,75 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   }
 }
 
-// ---- two-pass path for 2^15 <= N <= 2^17 (f32) -------------------------------------------------
-// N = Na * Nb with BALANCED factors (128..512 each) instead of N1 * 16384: input index n = n1*Nb + n2,
-// output index k = k1 + Na*k2,
-//   X[k1 + Na k2] = sum_n2 W_Nb^(n2 k2) * [ W_N^(n2 k1) * sum_n1 x[n1 Nb + n2] W_Na^(n1 k1) ].
-//   pass 1 (COLS): the Na-point transforms down the columns, times W_N^(n2 k1), written back in place of
-//                  the matrix [k1][n2] (scratch);
-//   pass 2 (ROWS): the Nb-point transforms along the rows k1, written TRANSPOSED to k1 + Na*k2.
-// Two passes over HBM (32 B per sample of traffic for 16 algorithmic) where the fused-columns four-step
-// of round 1 made three (N1-point columns / 16384-point rows / transposing copy).  A 256-thread workgroup
-// owns TILE = 32 (16 for 512-point transforms) columns / rows at a time: the strided side of each pass
-// moves TILE consecutive floats per matrix row -- 128-byte (64-byte) segments, 16 bytes per lane -- and the
-// transposition happens in LDS, where the tile's transforms also run (fft_passes on TILE LDS rows, 256/TP
-// rows per round).  LDS rows are LROW + 2 elements apart: (L + L/16) is a multiple of 8 for L >= 128, and
-// four rows must not land on the same banks when a lane quad writes one element to each of four rows.
+// ---- tile passes: two passes for 2^15 <= N <= 2^17, three for 2^19 <= N <= 2^27 (f32) -----------
+// N is cut into BALANCED factors of 64 ... 512 points instead of N1 * 16384, and every pass is one launch
+// of tile_pass_kernel: a 256-thread workgroup owns TILE transforms of one factor, moves them between HBM
+// and LDS in 128 ... 256-byte segments, runs them in LDS (fft_passes on the tile's LDS rows, 256/TP rows
+// per round), and writes them back -- the transposition that a multi-pass transform needs happens in LDS.
+//
+// Two passes, N = A*B: n = n1*B + n2, k = k1 + A*k2,
+//   X[k1 + A k2] = sum_n2 W_B^(n2 k2) * [ W_N^(n2 k1) * sum_n1 x[n1 B + n2] W_A^(n1 k1) ].
+//   pass 1 (COLS): A-point transforms down the columns n2, times W_N^(n2 k1), written back in place of
+//                  the matrix [k1][n2];
+//   pass 2 (ROWS): B-point transforms along the rows k1, written TRANSPOSED to k1 + A*k2.
+// Three passes, N = A*B*C: n = (n1*B + n2)*C + n3, k = k1 + A*(k2 + B*k3); with n' = n2*C + n3,
+//   W_N^(n k) = W_A^(n1 k1) * W_N^(n' k1) * W_B^(n2 k2) * W_BC^(n3 k2) * W_C^(n3 k3):
+//   pass 1 (COLS): A-point transforms over n1 (stride B*C) for every column n', times W_N^(n' k1), in place;
+//   pass 2 (COLS): for every k1, B-point transforms over n2 (stride C) for every n3, times
+//                  W_BC^(n3 k2) = W_N^(A n3 k2), written to row k2*A + k1 (so that pass 3 finds rows of
+//                  consecutive k1 next to each other);
+//   pass 3 (ROWS): C-point transforms along the rows, written transposed to (k2*A + k1) + A*B*k3.
+// HBM traffic is 16 B per sample per pass (32 / 48 B for 16 algorithmic) where round 1's forms made three
+// passes (N1 <= 16 columns / 16384-point rows / transposing copy) up to 2^18 and five above.
+//
+// Geometry of one launch (TileGeom): blockIdx -> (batch row b, block blk < nblk, tile < tiles);
+//   COLS: element (p, j), p < L, j < TILE:  in[b*N + blk*in_blk + tile*TILE + p*in_stride + j]
+//                                          out[b*N + blk*out_blk + tile*TILE + p*out_stride + j]
+//         times W_N^(tmul * (tile*TILE + j) * p);
+//   ROWS: TILE whole rows of L contiguous points from in[b*N + tile*TILE*L]; row i, output p goes to
+//         out[b*N + tile*TILE + i + p*out_stride], times `scale`.
+// LDS rows are LROWX = LROW + (2 - LROW) mod 8 elements apart: a lane quad writes one element to each of
+// four rows, and four rows of LROW (a multiple of 8 for L >= 128) would land on the same banks.
 //   tw = radix table of the L-point transform; W_N^m = twa[m >> 9] * twb[m & 511].
-//   COLS: in = [L rows][other = Nb] (strided tile), out = same layout.   in_im may be null (real input).
-//   ROWS: in = [TILE rows of L contiguous points], out[p * other + row], other = Na; times `scale`.
+struct TileGeom {
+  long long n;          // N
+  int nblk, tiles;      // blocks per transform, tiles per block
+  long long in_blk, out_blk, in_stride, out_stride;
+  unsigned tmul;        // twiddle exponent multiplier (1, or A in the middle pass of three)
+};
+
 template <typename T, int LOG2L, int TILE, bool COLS, bool REAL_IN = false>
 __global__ void __launch_bounds__(256)
-twopass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
-               const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
-               const cx<T> *__restrict__ twb, const int other, const T scale, const long long batch) {
+tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
+                 const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
+                 const cx<T> *__restrict__ twb, const TileGeom g, const T scale, const long long batch) {
   using TR = FftTraits<LOG2L>;
   constexpr int L = TR::N, E = TR::E, TP = TR::TP, RPR = 256 / TP, ROUNDS = TILE / RPR;
-  static_assert(LOG2L >= 7 && LOG2L <= 9 && TILE % RPR == 0 && TILE % 4 == 0, "tile of whole rounds");
-  constexpr int LROWX = TR::LROW + 2;
+  static_assert(LOG2L >= 6 && LOG2L <= 9 && TILE % RPR == 0 && TILE % 4 == 0 && ROUNDS >= 1, "tile of whole rounds");
+  constexpr int LROWX = TR::LROW + ((2 - TR::LROW % 8) + 8) % 8;
   constexpr int TS = TILE / 4, SPI = 256 / TS;  // threads per tile segment, segments per wave of accesses
   static_assert(L % SPI == 0, "whole accesses");
   typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ cx<T> lds[TILE * LROWX];
 
   const int t = (int)threadIdx.x;
-  const int tiles = other / TILE;
-  const long long b = (long long)blockIdx.x / tiles;
-  const int t0 = (int)((long long)blockIdx.x % tiles) * TILE;
+  const long long per = (long long)g.nblk * g.tiles;
+  const long long b = (long long)blockIdx.x / per;
+  const int rem = (int)((long long)blockIdx.x % per);
+  const int blk = rem / g.tiles, t0 = (rem % g.tiles) * TILE;
   if (b >= batch) return;
-  const size_t nn = (size_t)L * (size_t)other;  // N
-  const size_t base = (size_t)b * nn;
+  const size_t base = (size_t)b * (size_t)g.n;
   const int seg = t / TS, j4 = (t % TS) * 4;
 
   if constexpr (COLS) {
-    // strided tile in: element (p, j) = in[p*other + t0 + j] -> LDS row j, position p
+    // strided tile in: element (p, j) -> LDS row j, position p
+    const size_t ibase = base + (size_t)blk * (size_t)g.in_blk + (size_t)(t0 + j4);
     static_for<L / SPI>([&](auto ic) {
       const int p = seg + SPI * ic;
-      const size_t g = base + (size_t)p * (size_t)other + (size_t)(t0 + j4);
-      const V4 r = ld_stream(reinterpret_cast<const V4 *>(in_re + g));
+      const size_t gi = ibase + (size_t)p * (size_t)g.in_stride;
+      const V4 r = ld_stream(reinterpret_cast<const V4 *>(in_re + gi));
       V4 m = V4{T(0), T(0), T(0), T(0)};
-      if constexpr (!REAL_IN) m = ld_stream(reinterpret_cast<const V4 *>(in_im + g));
+      if constexpr (!REAL_IN) m = ld_stream(reinterpret_cast<const V4 *>(in_im + gi));
       cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
       d[0 * LROWX] = cx<T>{r.x, m.x};
       d[1 * LROWX] = cx<T>{r.y, m.y};
@@ -1857,16 +1878,18 @@ twopass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__re
   });
   __syncthreads();
 
-  // strided tile out: element (p, j) -> out[p*other + t0 + j]
+  // strided tile out: element (p, j) -> out[... + p*out_stride + j]
+  const size_t obase = COLS ? base + (size_t)blk * (size_t)g.out_blk + (size_t)(t0 + j4) : base + (size_t)(t0 + j4);
   static_for<L / SPI>([&](auto ic) {
     const int p = seg + SPI * ic;
     const cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
     cx<T> v[4] = {d[0 * LROWX], d[1 * LROWX], d[2 * LROWX], d[3 * LROWX]};
     if constexpr (COLS) {
-      // W_N^((t0 + j4 + j) p), j = 0..3: one two-level lookup for j = 0, then steps of W_N^p (p < 512: twb[p])
-      const unsigned m = (unsigned)(t0 + j4) * (unsigned)p;  // < N <= 2^18
+      // W_N^(tmul (t0 + j4 + j) p), j = 0..3: one two-level lookup for j = 0, then steps of W_N^(tmul p)
+      const unsigned mp = g.tmul * (unsigned)p;                 // < N
+      const unsigned m = mp * (unsigned)(t0 + j4);              // < N <= 2^27
       cx<T> w = cmul(twa[m >> 9], twb[m & 511]);
-      const cx<T> ws = twb[p];
+      const cx<T> ws = cmul(twa[mp >> 9], twb[mp & 511]);
       v[0] = cmul(v[0], w);
       static_for<3>([&](auto jc) {
         w = cmul(w, ws);
@@ -1875,9 +1898,9 @@ twopass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__re
     } else {
       static_for<4>([&](auto jc) { v[jc] = v[jc] * scale; });
     }
-    const size_t g = base + (size_t)p * (size_t)other + (size_t)(t0 + j4);
-    st_stream(V4{v[0].x, v[1].x, v[2].x, v[3].x}, reinterpret_cast<V4 *>(out_re + g));
-    st_stream(V4{v[0].y, v[1].y, v[2].y, v[3].y}, reinterpret_cast<V4 *>(out_im + g));
+    const size_t go = obase + (size_t)p * (size_t)g.out_stride;
+    st_stream(V4{v[0].x, v[1].x, v[2].x, v[3].x}, reinterpret_cast<V4 *>(out_re + go));
+    st_stream(V4{v[0].y, v[1].y, v[2].y, v[3].y}, reinterpret_cast<V4 *>(out_im + go));
   });
 }
 

@@ -127,20 +127,22 @@ def test_general_four_step_n_2_24(oracle_mod):
         del plan, dre, dim, ore, oim, bre, bim
 
 
-@pytest.mark.parametrize("log2n", [15, 16, 17, 18])
-def test_twopass_vs_threepass_vs_oracle(pdsp, oracle_mod, log2n):
-    """2^15 <= N <= 2^17 in f32 (2^18 stays on the three-pass form either way): twopass_kernel (N = Na * Nb, balanced factors, two passes over HBM) against
-    the three-pass fused-columns four-step (pdsp_set_twopass(0)) and the oracle: complex, real input,
-    inverse, an in-place call (output planes = input planes) and a batch that is not a multiple of anything."""
+@pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
+    """f32 transforms beyond the single-pass limit on tile_pass_kernel -- balanced factors, two passes over
+    HBM for 2^15 <= N <= 2^17 and three for 2^19 <= N <= 2^27 (2^18 stays on the four-step form either
+    way) -- against round 1's four-step forms (pdsp_set_twopass(0): three / five passes) and the oracle:
+    complex, real input, inverse, an in-place call (output planes = input planes) and an odd batch."""
     import torch
     from pragma_dsp_amd.batch import BatchedFft
-    n, batch = 1 << log2n, 5
+    n, batch = 1 << log2n, (5 if log2n <= 20 else 3 if log2n <= 22 else 2)
     rng = np.random.default_rng(100 + log2n)
     re = rng.standard_normal((batch, n)).astype(np.float32)
     im = rng.standard_normal((batch, n)).astype(np.float32)
-    re[1] = 0.0
-    im[1] = 0.0
-    re[1, 3] = 1.0                                       # an impulse row: |X| = 1 everywhere
+    imp = batch - 1
+    re[imp] = 0.0
+    im[imp] = 0.0
+    re[imp, 3] = 1.0                                     # an impulse row: |X| = 1 everywhere
     plan = BatchedFft(n, "cuda:0")
     wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
     want = wre + 1j * wim
@@ -153,10 +155,11 @@ def test_twopass_vs_threepass_vs_oracle(pdsp, oracle_mod, log2n):
             ore, oim = plan.forward(dre, dim)
             got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
             assert rel_err(got, want) <= 1e-5
-            assert np.abs(np.abs(got[1]) - 1.0).max() < 1e-5
+            assert np.abs(np.abs(got[imp]) - 1.0).max() < 1e-5
             bre, bim = plan.inverse(ore, oim)
-            assert np.abs(bre.cpu().numpy() - re).max() <= 1e-5 * np.abs(re).max() * 4
-            assert np.abs(bim.cpu().numpy() - im).max() <= 1e-5 * np.abs(im).max() * 4
+            top = max(np.abs(re).max(), np.abs(im).max())
+            assert np.abs(bre.cpu().numpy() - re).max() <= 1e-5 * top * 4
+            assert np.abs(bim.cpu().numpy() - im).max() <= 1e-5 * top * 4
             rre, rim = plan.forward(dre)                  # Radix2Fft.forward: real input
             assert rel_err(rre.cpu().numpy().astype(np.float64) + 1j * rim.cpu().numpy(), rre_w + 1j * rim_w) <= 1e-5
             plan.forward(dre, dim, out=(dre, dim))        # in place

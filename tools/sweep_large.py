@@ -32,12 +32,12 @@ for log2n in (15, 16, 17, 18, 19, 20, 22, 24, 26):
     ore, oim = torch.empty_like(re), torch.empty_like(im)
     t = timed(lambda: plan.forward(re, im, out=(ore, oim)))
     c = 16.0 * batch * n / t / 1e9
-    line = f"{n:10d} {2 if log2n <= 17 else (3 if log2n == 18 else 5):7d} {c:10.0f} {c/8000:6.3f} {batch*n/t/1e9:10.1f}"
-    if log2n <= 18:  # A/B: the three-pass fused-columns form of round 1
+    line = f"{n:10d} {2 if log2n <= 17 else 3:7d} {c:10.0f} {c/8000:6.3f} {batch*n/t/1e9:10.1f}"
+    if True:  # A/B: round 1's four-step forms (three passes up to 2^18, five above)
         from pragma_dsp_amd import _capi
         prev = _capi.lib.pdsp_set_twopass(0)
         t3 = timed(lambda: plan.forward(re, im, out=(ore, oim)))
         _capi.lib.pdsp_set_twopass(prev)
-        line += f"   (three-pass: {16.0 * batch * n / t3 / 1e9:6.0f} GB/s)"
+        line += f"   (round-1 four-step: {16.0 * batch * n / t3 / 1e9:6.0f} GB/s)"
     print(line, flush=True)
     del re, im, ore, oim, plan
