@@ -899,7 +899,11 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
 #ifndef PDSP_PACKED_ADJ
 #define PDSP_PACKED_ADJ 1  /* 0: round-1 split (bins tid + TP*q, dword stores in two directions): A/B builds */
 #endif
-  constexpr bool kAdj = FAST && LOG2E == 4 && PDSP_PACKED_ADJ;
+  // adjacent-bin 8-byte non-temporal stores pay when a wave's stores cover whole cache lines of one row
+  // (TP >= 32: N >= 1024).  Below that a wave spans many short rows and each lane's 8 / 16 bytes would be
+  // a partial-line streaming write: measured 1.8 -> 0.8 TB/s at N = 64 (f32, staged path off) and
+  // 36 -> 22 % in f64 -- those sizes keep round 1's split (dword stores that L2 merges).
+  constexpr bool kAdj = FAST && LOG2E == 4 && TP >= 32 && PDSP_PACKED_ADJ;
   typedef T V4 __attribute__((ext_vector_type(4)));
 
   __shared__ cx<T> lds[TR::LDS_ELEMS];
