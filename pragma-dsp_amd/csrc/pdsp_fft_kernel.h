@@ -936,6 +936,9 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     }
     load_order_fence();
   }
+  // (Buffer-form addressing -- one descriptor per row, scalar q offsets -- gains 4-5 % on the N = 16384
+  // kernel, where it removes ~100 address instructions; here, A/B with tools/sweep.py, it measured +-0 at
+  // N = 2048 / 8192 and -2 % at 4096, so the flat form stays.)
   if constexpr (FAST) {
     const cx<T> *const x2 = reinterpret_cast<const cx<T> *>(xrow);
     static_for<E>([&](auto q) { x[q] = ld_stream(x2 + TP * q + (unsigned)tid); });
@@ -1644,13 +1647,31 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   if constexpr (WIN >= 2) wb4 = reinterpret_cast<const V4 *>(wf.base)[(unsigned)tid];
   load_order_fence();
 
-  // z[m], z[m + 4096], m = tid + 256q: 8-byte non-temporal loads, unit stride across the lanes
+  // z[m], z[m + 4096], m = tid + 256q: 8-byte non-temporal loads, unit stride across the lanes.
+  // Buffer form (PDSP_DIF_BUFFER): one descriptor for the frame, ONE per-lane offset register (8 tid) and
+  // the 2048 q (+ 32768) part as a scalar offset -- with flat addresses hipcc built a 64-bit vector address
+  // per load (v_add_co / s_nop / v_addc: the q offsets exceed the 13-bit immediate), ~100 of the kernel's
+  // ~1300 issue slots, on a kernel whose vector issue is its busiest resource.
+#ifndef PDSP_DIF_BUFFER
+#define PDSP_DIF_BUFFER 1
+#endif
   const cx<T> *const z2 = reinterpret_cast<const cx<T> *>(frames + (size_t)row * (size_t)stride);
   cx<T> a[E], b[E];
-  static_for<E>([&](auto q) {
-    a[q] = ld_stream(z2 + TP * q + (unsigned)tid);
-    b[q] = ld_stream(z2 + H + TP * q + (unsigned)tid);
-  });
+  if constexpr (PDSP_DIF_BUFFER && sizeof(T) == 4) {
+    typedef unsigned U2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<cx<T> *>(z2), 0, 2 * M * (int)sizeof(T), 0x00020000);
+    const int vo = tid * 8;
+    static_for<E>([&](auto q) {
+      a[q] = __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 2048 * q, 2 /* nt */));
+      b[q] = __builtin_bit_cast(cx<T>, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 32768 + 2048 * q, 2));
+    });
+  } else {
+    static_for<E>([&](auto q) {
+      a[q] = ld_stream(z2 + TP * q + (unsigned)tid);
+      b[q] = ld_stream(z2 + H + TP * q + (unsigned)tid);
+    });
+  }
   load_order_fence();
   if constexpr (HAS_WIN) {
     static_for<E>([&](auto q) {
@@ -1700,6 +1721,11 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   T dc_amp = T(0);
   cx<T> dc_x{T(0), T(0)};
   typedef T V2 __attribute__((ext_vector_type(2)));
+  // amplitude row as a buffer: pairs (2k, 2k+1) at byte 8 tid + 2048 q, mirrors (8191-2k, 8192-2k) at
+  // byte 4 (M-1) - 8 tid - 2048 q = [4 (M-1) - 2048*7 - 8 tid] + 2048 (7 - q): two per-lane offsets, scalar rest
+  typedef unsigned U2s __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(arow, 0, (M + 1) * (int)sizeof(T), 0x00020000);
+  const int vo_lo = tid * 8, vo_hi = 4 * (M - 1) - 2048 * 7 - tid * 8;
   static_for<E / 2>([&](auto qc) {
     constexpr int q = qc;
     const int k = tid + TP * q;  // < 2048
@@ -1734,8 +1760,13 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       best.consider(mbe, M - 2 * k, xbe);
     }
     if (store_amp) {
-      __builtin_nontemporal_store(V2{mae, mao}, reinterpret_cast<V2 *>(arow + (unsigned)(2 * k)));
-      __builtin_nontemporal_store(V2{mbo, mbe}, reinterpret_cast<V2 *>(arow + (unsigned)(M - 1 - 2 * k)));
+      if constexpr (PDSP_DIF_BUFFER && sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mae, mao}), ws, vo_lo, 2048 * q, 2 /* nt */);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mbo, mbe}), ws, vo_hi, 2048 * (7 - q), 2);
+      } else {
+        __builtin_nontemporal_store(V2{mae, mao}, reinterpret_cast<V2 *>(arow + (unsigned)(2 * k)));
+        __builtin_nontemporal_store(V2{mbo, mbe}, reinterpret_cast<V2 *>(arow + (unsigned)(M - 1 - 2 * k)));
+      }
     }
   });
   // the middle bin 4096 = 2*2048 pairs with itself: X[4096] = conj(Z[4096]) = conj(U[2048])
