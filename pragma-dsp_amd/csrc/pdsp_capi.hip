@@ -1106,7 +1106,7 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     // A window that is one of the PLAN'S OWN tables (pdsp_plan_window_f32) is known by kind: the kernels
     // that can (whole f32 frames, N = 1024 ... 16384) then evaluate the cosine sum in registers.
     // wmode: 0 rect, 1 table, 2 / 3 fused two- / three-term cosine sum.
-    pdsp::WinFused wf{nullptr, nullptr, 0.f, 0.f, 0.f};
+    pdsp::WinFused wf{nullptr, nullptr, 0.f, 0.f, 0.f, 1.f};
     int wmode = window ? 1 : 0;
     if constexpr (sizeof(T) == 4) {
       int kind = -1;  // -1: caller's table
@@ -1118,6 +1118,11 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
         if (kind == PDSP_WIN_HANN) wmode = 2, wf.k0 = 0.5f, wf.k1 = -0.5f;
         else if (kind == PDSP_WIN_HAMMING) wmode = 2, wf.k0 = 0.54f, wf.k1 = -0.46f;
         else if (kind == PDSP_WIN_BLACKMAN) wmode = 3, wf.k0 = 0.42f - 0.08f, wf.k1 = -0.5f, wf.k2 = 2 * 0.08f;
+        if (wmode >= 2) {  // the kernels take the fused coefficients pre-scaled by s_mid / 2 (a power of two: exact)
+          const float g = 0.5f * (float)s_mid;
+          wf.k0 *= g, wf.k1 *= g, wf.k2 *= g;
+          wf.edge_ratio = (float)(s_edge / s_mid);
+        }
       }
     }
     if constexpr (sizeof(T) == 4) {

@@ -863,6 +863,10 @@ struct WinFused {
   const float *base;  // [TP][4]: cos, sin of f*(2 tid), cos, sin of f*(2 tid + 1)
   const float *step;  // [16][2]: cos, sin of f*2 TP q (q < 16); N = 16384 kernel: [32][2], the second half for + N/2
   float k0, k1, k2;
+  // the coefficients above already carry the amplitude scale s_mid / 2 (a power of two: exact), so the
+  // Hermitian split multiplies by nothing; edge_ratio = s_edge / s_mid fixes up the two bins that are
+  // not doubled (DC, Nyquist)
+  float edge_ratio;
 };
 
 // Fused body of spectrum() for real frames, one frame per row, via the packed-real
@@ -958,14 +962,19 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     load_order_fence();
     if constexpr (HAS_WIN) static_for<E>([&](auto q) { x[q] = x[q] * wv[q]; });
     if constexpr (WIN >= 2) {
+      static_assert(WIN < 2 || kAdj, "the fused windows' pre-scaled frames are split by the adjacent-bin code");
       const cx<T> cb{wb4.x, wb4.z}, sb{wb4.y, wb4.w};  // (e = 0, e = 1)
-      const T k0 = wf.k0, k1 = wf.k1, k2 = wf.k2;
+      const T k0 = wf.k0, k1 = wf.k1, k2 = wf.k2;        // pre-scaled by s_mid / 2 on the host (WinFused)
+      const cx<T> kc = cb * k1, ks = sb * k1;             // two-term form: w = k0 + kc cos_q - ks sin_q
       static_for<E>([&](auto qc) {
         constexpr int q = qc;
         const T cq = wf.step[2 * q], sq = wf.step[2 * q + 1];  // wave-uniform: scalar loads
-        const cx<T> c = cb * cq - sb * sq;                     // cos(f n), n = 2 (tid + TP q) + e
-        if constexpr (WIN == 3) x[q] = x[q] * (k0 + c * (k1 + k2 * c));
-        else x[q] = x[q] * (k0 + k1 * c);
+        if constexpr (WIN == 3) {
+          const cx<T> c = cb * cq - sb * sq;                   // cos(f n), n = 2 (tid + TP q) + e
+          x[q] = x[q] * (k0 + c * (k1 + k2 * c));
+        } else {
+          x[q] = x[q] * ((k0 + kc * cq) - ks * sq);
+        }
       });
     }
   } else {
@@ -1009,11 +1018,24 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       const cx<T> z0 = lrow[lds_pad(k0)], z1 = lrow[lds_pad(k0) + 1];          // k0 % 16 <= 14: same block of 16
       const cx<T> zp0 = lrow[lds_pad((M - k0) & (M - 1))], zp1 = lrow[lds_pad(M - k0 - 1)];
       const cx<T> w0 = mul_w32<T, 2 * q>(tw0), w1 = mul_w32<T, 2 * q>(tw1);
-      const T h0 = T(0.5) * ((k0 == 0) ? s_edge : s_mid), h1 = T(0.5) * s_mid;
-      const cx<T> e0 = (z0 + conj(zp0)) * h0, p0 = cmul(z0 - conj(zp0), w0) * h0;
-      const cx<T> e1 = (z1 + conj(zp1)) * h1, p1 = cmul(z1 - conj(zp1), w1) * h1;
-      const cx<T> xa0 = add_mul_neg_i(e0, p0), xb0 = conj(add_mul_pos_i(e0, p0));  // X[k0], X[M - k0]
+      cx<T> e0, p0, e1, p1;
+      if constexpr (WIN >= 2) {
+        // the frame came in pre-scaled by s_mid / 2 (folded into the fused window's coefficients): no
+        // multiplies here; DC and Nyquist (k0 = 0: not doubled) are fixed up on xa0 / xb0 below
+        e0 = z0 + conj(zp0), p0 = cmul(z0 - conj(zp0), w0);
+        e1 = z1 + conj(zp1), p1 = cmul(z1 - conj(zp1), w1);
+      } else {
+        const T h0 = T(0.5) * ((k0 == 0) ? s_edge : s_mid), h1 = T(0.5) * s_mid;
+        e0 = (z0 + conj(zp0)) * h0, p0 = cmul(z0 - conj(zp0), w0) * h0;
+        e1 = (z1 + conj(zp1)) * h1, p1 = cmul(z1 - conj(zp1), w1) * h1;
+      }
+      cx<T> xa0 = add_mul_neg_i(e0, p0), xb0 = conj(add_mul_pos_i(e0, p0));        // X[k0], X[M - k0]
       const cx<T> xa1 = add_mul_neg_i(e1, p1), xb1 = conj(add_mul_pos_i(e1, p1));  // X[k0 + 1], X[M - k0 - 1]
+      if constexpr (WIN >= 2 && q == 0) {
+        const T r = tid == 0 ? T(wf.edge_ratio) : T(1);  // k0 = 0 lives in thread 0's first pair
+        xa0 = xa0 * r;
+        xb0 = xb0 * r;
+      }
       const T ma0 = mag(xa0), mb0 = mag(xb0), ma1 = mag(xa1), mb1 = mag(xb1);
       if constexpr (PEAK) {
         if (k0 == 0) {
@@ -1032,7 +1054,7 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       }
     });
     if (tid == 0) {  // the middle bin M/2 pairs with itself: X[M/2] = conj(Z[M/2]) scaled
-      const cx<T> xm = conj(lrow[lds_pad(M / 2)]) * s_mid;
+      const cx<T> xm = conj(lrow[lds_pad(M / 2)]) * (WIN >= 2 ? T(2) : s_mid);  // pre-scaled frames carry s_mid / 2
       const T mm = mag(xm);
       if constexpr (PEAK) best.consider(mm, M / 2, xm);
       if (store_amp) st_rowtail(mm, arow + (unsigned)(M / 2));
@@ -1681,17 +1703,18 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   }
   if constexpr (WIN >= 2) {
     const cx<T> cb{wb4.x, wb4.z}, sb{wb4.y, wb4.w};  // (e = 0, e = 1)
-    const T k0 = wf.k0, k1 = wf.k1, k2 = wf.k2;
+    const T k0 = wf.k0, k1 = wf.k1, k2 = wf.k2;        // pre-scaled by s_mid / 2 on the host (WinFused)
+    const cx<T> kc = cb * k1, ks = sb * k1;             // two-term form: w = k0 + kc cos_q - ks sin_q
     static_for<E>([&](auto qc) {
       constexpr int q = qc;
       const T cl = wf.step[2 * q], sl = wf.step[2 * q + 1], ch = wf.step[32 + 2 * q], sh = wf.step[32 + 2 * q + 1];
-      const cx<T> c_lo = cb * cl - sb * sl, c_hi = cb * ch - sb * sh;  // cos(f n), n = 2m + e and + 8192
       if constexpr (WIN == 3) {
+        const cx<T> c_lo = cb * cl - sb * sl, c_hi = cb * ch - sb * sh;  // cos(f n), n = 2m + e and + 8192
         a[q] = a[q] * (k0 + c_lo * (k1 + k2 * c_lo));
         b[q] = b[q] * (k0 + c_hi * (k1 + k2 * c_hi));
       } else {
-        a[q] = a[q] * (k0 + k1 * c_lo);
-        b[q] = b[q] * (k0 + k1 * c_hi);
+        a[q] = a[q] * ((k0 + kc * cl) - ks * sl);
+        b[q] = b[q] * ((k0 + kc * ch) - ks * sh);
       }
     });
   }
@@ -1739,14 +1762,27 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     const cx<T> zpo = lds[Q + (Q - 1) - TP * q - tid];
     const cx<T> we = mul_w32<T, q>(wc0);  // W_16384^(2k)
     const cx<T> wo = mul_w32<T, q>(ws1);  // W_16384^(2k+1)
-    // the amplitude scale rides on the 1/2 of the split (DC and Nyquist, k = 0, are not doubled)
-    const T he = T(0.5) * ((k == 0) ? s_edge : s_mid), ho = T(0.5) * s_mid;
-    const cx<T> ee = (ze + conj(zpe)) * he, pe = cmul(ze - conj(zpe), we) * he;
-    const cx<T> eo = (zo + conj(zpo)) * ho, po = cmul(zo - conj(zpo), wo) * ho;
-    const cx<T> xae = add_mul_neg_i(ee, pe);        // scaled X[2k]
-    const cx<T> xbe = conj(add_mul_pos_i(ee, pe));  // scaled X[8192 - 2k]
+    cx<T> ee, pe, eo, po;
+    if constexpr (WIN >= 2) {
+      // the frame came in pre-scaled by s_mid / 2 (folded into the fused window's coefficients): no
+      // multiplies here; DC and Nyquist (k = 0: not doubled) are fixed up on the two magnitudes below
+      ee = ze + conj(zpe), pe = cmul(ze - conj(zpe), we);
+      eo = zo + conj(zpo), po = cmul(zo - conj(zpo), wo);
+    } else {
+      // the amplitude scale rides on the 1/2 of the split (DC and Nyquist, k = 0, are not doubled)
+      const T he = T(0.5) * ((k == 0) ? s_edge : s_mid), ho = T(0.5) * s_mid;
+      ee = (ze + conj(zpe)) * he, pe = cmul(ze - conj(zpe), we) * he;
+      eo = (zo + conj(zpo)) * ho, po = cmul(zo - conj(zpo), wo) * ho;
+    }
+    cx<T> xae = add_mul_neg_i(ee, pe);        // scaled X[2k]
+    cx<T> xbe = conj(add_mul_pos_i(ee, pe));  // scaled X[8192 - 2k]
     const cx<T> xao = add_mul_neg_i(eo, po);        // scaled X[2k + 1]
     const cx<T> xbo = conj(add_mul_pos_i(eo, po));  // scaled X[8191 - 2k]
+    if constexpr (WIN >= 2 && q == 0) {
+      const T r = tid == 0 ? T(wf.edge_ratio) : T(1);  // k = 0 lives in thread 0's first pair
+      xae = xae * r;
+      xbe = xbe * r;
+    }
     const T mae = mag(xae), mbe = mag(xbe), mao = mag(xao), mbo = mag(xbo);
     if constexpr (PEAK) {
       if (k == 0) {
@@ -1772,7 +1808,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   // the middle bin 4096 = 2*2048 pairs with itself: X[4096] = conj(Z[4096]) = conj(U[2048])
   if (tid == 0) {
     const cx<T> xm = conj(umid);
-    const T mm = mag(xm) * s_mid;
+    const T mm = mag(xm) * (WIN >= 2 ? T(2) : s_mid);  // pre-scaled frames carry s_mid / 2 already
     if constexpr (PEAK) best.consider(mm, H, xm);
     if (store_amp) st_rowtail(mm, arow + (unsigned)H);
   }

@@ -112,9 +112,9 @@ static int spec_main(long long frames, int rounds) {
   std::vector<SV> svs;
   svs.push_back({"packed<13>", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, 1, false>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
-                       dim3(TR::WG), 0, 0, x, win, pdsp::WinFused{nullptr, nullptr, 0.f, 0.f, 0.f}, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
+                       dim3(TR::WG), 0, 0, x, win, pdsp::WinFused{nullptr, nullptr, 0.f, 0.f, 0.f, 1.f}, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
                        1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
-  pdsp::WinFused wfz{nullptr, nullptr, 0.f, 0.f, 0.f}, wfh = wfz;
+  pdsp::WinFused wfz{nullptr, nullptr, 0.f, 0.f, 0.f, 1.f}, wfh = wfz;
   {
     const double f = 2 * M_PI / (n - 1);
     std::vector<float> hb(256 * 4), hs(64);
@@ -132,7 +132,7 @@ static int spec_main(long long frames, int rounds) {
     CK(hipMalloc(&dsx, hs.size() * 4));
     CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dsx, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
-    wfh = pdsp::WinFused{db, dsx, 0.5f, -0.5f, 0.0f};
+    wfh = pdsp::WinFused{db, dsx, 0.5f / n, -0.5f / n, 0.0f, 0.5f};  // pre-scaled by s_mid / 2 = 1/N (one-sided)
   }
   svs.push_back({"dif16k (x2 ld, x2 nt st)", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 1, false>), dim3(frames), dim3(256), 0, 0, x, win, wfz,
