@@ -10,7 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-traffic = {}
+tpath = os.path.join(ROOT, "profiles", "traffic.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}  # merged: a partial re-profile updates its kernels only
 for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*"))):
     if not os.path.isdir(d):
         continue
@@ -22,10 +23,10 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*"))):
     if os.path.exists(summ) and os.path.getsize(summ) > 0:
         shutil.copy(summ, os.path.join(ROOT, "profiles", f"{name}_summary.json"))
         for k, v in json.load(open(summ))["kernels"].items():
-            if "hbm_bytes_per_launch" in v and v.get("pct", 0) > 20 and k not in traffic:  # the workload's dominant kernel(s)
+            if "hbm_bytes_per_launch" in v and v.get("pct", 0) > 20:  # the workload's dominant kernel(s)
                 traffic[k] = {x: v[x] for x in ("hbm_bytes_per_launch", "hbm_read_bytes", "hbm_write_bytes", "avg_ns")}
                 traffic[k]["source"] = f"profiles/{name}_summary.json"
     print(name, "stats" if stats else "-", "summary" if os.path.exists(summ) else "-")
 if traffic:
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(tpath, "w"), indent=1)
     print("traffic.json:", len(traffic), "kernels")
