@@ -1606,7 +1606,8 @@ fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
 // 4096-point transforms that the same 256 threads run back to back through one 4096-point LDS buffer
 // (spectrum_packed_kernel<13> needs 69.6 KB of LDS per frame and 5 full-size LDS round trips; here
 // 34.8 KB and 2.5).  Round 1 made the cut by decimation in TIME (16-byte loads, Z[k] / Z[k+4096] in
-// registers, dword stores): same arithmetic, 5.05 TB/s; this cut: 5.7 (fused Hann window).
+// registers, dword stores): same arithmetic, 4.65-5.05 TB/s by box; this cut, with the fused Hann window,
+// buffer addressing and the scale folded into the window: 5.6-6.0.
 //   u[m] = z[m] + z[m+4096],  v[m] = (z[m] - z[m+4096]) * W_8192^m,   m < 4096;
 //   U = FFT_4096(u) = the even bins Z[2k],  V = FFT_4096(v) = the odd bins Z[2k+1].
 // The radix-2 step sits in front of the sub-transforms, which shapes the memory accesses at both ends
