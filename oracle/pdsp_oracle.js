@@ -8,7 +8,14 @@
 // (src/core/fft.ts:25-38, 45-61, 110-148) -- written from that description, not copied.
 // Pinned against the reference's goldens by tests/test_oracle_golden.py::test_node_oracle_*.
 //
+// Also the whole one-shot spectrum() call (src/public/spectrum.ts:107-142) restated WITH its per-call
+// costs -- a fresh plan (bit-reversal table + 2(N-1) cos/sin: fft.ts:25-61, rebuilt by `new FFT` on
+// every call, spectrum.ts:114), a fresh window (fourier.ts:14-52), Math.hypot / Math.atan2 per bin
+// (fourier.ts:98-120), the scaling, frequency axis and findPeak -- so that the drop-in's one-frame
+// latency has the reference's own one-frame cost beside it, not just the bare transform.
+//
 //   node oracle/pdsp_oracle.js fft            < {"cases":[{"n","re","im"|null,"inverse"}]}  > outputs
+//   node oracle/pdsp_oracle.js spectrum       < {"cases":[{"samples","options"}]}           > results
 //   node oracle/pdsp_oracle.js time N ROWS S  -> {"transforms","seconds","checksum","node"}
 'use strict';
 
@@ -71,6 +78,73 @@ function transform(plan, re, im, outRe, outIm, inverse) {
   }
 }
 
+function makeWindow(type, n) {
+  if (!(n > 0)) throw new Error('Window size must be positive, got ' + n);
+  const w = new Float64Array(n);
+  if (n === 1) { w[0] = 1; return w; }
+  const d = n - 1;
+  for (let i = 0; i < n; i++) {
+    const f = (2 * Math.PI * i) / d;
+    if (type === 'rect') w[i] = 1;
+    else if (type === 'hann') w[i] = 0.5 * (1 - Math.cos(f));
+    else if (type === 'hamming') w[i] = 0.54 - 0.46 * Math.cos(f);
+    else if (type === 'blackman') w[i] = 0.42 - 0.5 * Math.cos(f) + 0.08 * Math.cos(2 * f);
+    else throw new Error('Unsupported window type: ' + type);
+  }
+  return w;
+}
+
+function nextPow2(n) {
+  if (n <= 1) return 1;
+  let p = 1;
+  while (p < n) p *= 2;
+  return p;
+}
+
+// One spectrum() call the way the reference makes it: nothing is cached between calls.
+function spectrum(samples, options) {
+  const o = options || {};
+  const sampleRate = o.sampleRate === undefined ? 1 : o.sampleRate;
+  const sides = o.sides === undefined ? 'one' : o.sides;
+  const n = o.fftSize === undefined ? nextPow2(samples.length) : o.fftSize;
+  const plan = makePlan(n);                                    // new FFT(targetSize)
+  const win = makeWindow(o.window === undefined ? 'rect' : o.window, n);
+  const frame = new Float64Array(n);                           // buildFrame: truncate / zero-pad
+  const lim = Math.min(n, samples.length);
+  for (let i = 0; i < lim; i++) frame[i] = samples[i] === undefined ? 0 : samples[i];
+  const windowed = new Float64Array(n);
+  for (let i = 0; i < n; i++) windowed[i] = frame[i] * win[i];
+  const re = new Float64Array(n), im = new Float64Array(n);
+  transform(plan, windowed, null, re, im, false);
+  const mag = new Float64Array(n), ang = new Float64Array(n);
+  for (let i = 0; i < n; i++) {
+    mag[i] = Math.hypot(re[i], im[i]);
+    ang[i] = Math.atan2(im[i], re[i]);
+  }
+  const bins = sides === 'one' ? Math.floor(n / 2) + 1 : n;
+  const amp = new Float64Array(bins);
+  const nyq = n % 2 === 0 ? n / 2 : -1;
+  for (let k = 0; k < bins; k++) {
+    if (sides !== 'one' || k === 0 || k === nyq) amp[k] = mag[k] / n;
+    else amp[k] = (2 * mag[k]) / n;
+  }
+  const phase = sides === 'one' ? ang.slice(0, bins) : ang;
+  if (!(n > 0)) throw new Error('FFT size must be positive, got ' + n);
+  if (!(sampleRate > 0)) throw new Error('Sample rate must be positive, got ' + sampleRate);
+  const freq = new Float64Array(bins);
+  for (let i = 0; i < bins; i++) freq[i] = (i * sampleRate) / n;
+  let maxIndex = 0, maxValue = amp[0], hasNonDc = false, nonDcIndex = 0, nonDcValue = 0;  // findPeak
+  for (let i = 1; i < bins; i++) {
+    const v = amp[i];
+    if (v > nonDcValue) { nonDcValue = v; nonDcIndex = i; }
+    if (v > 0) hasNonDc = true;
+    if (v > maxValue) { maxValue = v; maxIndex = i; }
+  }
+  const idx = hasNonDc ? nonDcIndex : maxIndex;
+  return { frequencies: freq, amplitude: amp, phase: phase,
+           peak: { index: idx, frequency: freq[idx], amplitude: amp[idx], phase: phase[idx] } };
+}
+
 function readStdin() {
   return require('fs').readFileSync(0, 'utf8');
 }
@@ -84,6 +158,15 @@ function main(argv) {
       const oRe = new Float64Array(cs.n), oIm = new Float64Array(cs.n);
       transform(plan, Float64Array.from(cs.re), cs.im ? Float64Array.from(cs.im) : null, oRe, oIm, !!cs.inverse);
       return { re: Array.from(oRe), im: Array.from(oIm) };
+    });
+    process.stdout.write(JSON.stringify({ results: res }));
+    return 0;
+  }
+  if (mode === 'spectrum') {
+    const req = JSON.parse(readStdin());
+    const res = req.cases.map(function (cs) {
+      const r = spectrum(cs.samples, cs.options);
+      return { frequencies: Array.from(r.frequencies), amplitude: Array.from(r.amplitude), phase: Array.from(r.phase), peak: r.peak };
     });
     process.stdout.write(JSON.stringify({ results: res }));
     return 0;
@@ -126,4 +209,4 @@ function main(argv) {
 }
 
 if (require.main === module) process.exitCode = main(process.argv);
-module.exports = { makePlan: makePlan, transform: transform };
+module.exports = { makePlan: makePlan, transform: transform, spectrum: spectrum };

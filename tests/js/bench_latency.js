@@ -61,7 +61,15 @@ for (const n of [1024, 2048, 4096, 16384]) {
     const r = p.spectrum(input, { sampleRate: 48000, fftSize: n, window: 'hann' });
     checksum += r.peak.amplitude;
   });
-  out.cases.push({ n: n, op: 'spectrum(hann, one-sided)', gpu_dropin: sp });
+  const srow = { n: n, op: 'spectrum(hann, one-sided)', gpu_dropin: sp };
+  if (cpu && cpu.spectrum) {
+    // the reference's own one-shot cost: plan and window rebuilt per call (spectrum.ts:114-116)
+    srow.node_cpu = timed(() => {
+      const r = cpu.spectrum(input, { sampleRate: 48000, fftSize: n, window: 'hann' });
+      checksum += r.peak.amplitude;
+    });
+  }
+  out.cases.push(srow);
 }
 // spectrumBatch: 256 frames per call
 for (const n of [1024, 4096]) {

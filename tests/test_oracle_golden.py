@@ -274,3 +274,36 @@ def test_oracle_spectrum_peak_vs_golden_peak_metadata(oracle_mod, reallife, mani
         assert w["peak"]["frequency"] == k * FS / N
         if float(c["peakMagnitude"]) > 1e-6:
             assert wrap(w["peak"]["phase"] - ph) < 1e-10, c["name"]
+
+
+def test_node_spectrum_restatement_matches_c_oracle_and_known_answers(oracle_mod, reallife):
+    """oracle/pdsp_oracle.js `spectrum()` -- the reference's one-shot call restated with its per-call plan
+    and window builds, used only as the CPU latency baseline of bench_latency.js -- against the C oracle
+    (itself pinned on the goldens) and the inline known answers of SURVEY 8(a)."""
+    import json, os, shutil, subprocess
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(9)
+    cases = [
+        ([0, 1, 0, -1, 0, 1, 0, -1], {"sampleRate": 48000}),
+        (reallife["sine_440hz/signal"].tolist(), {"sampleRate": 48000, "fftSize": 1024, "window": "hann"}),
+        (reallife["dc_plus_sine_bin8/signal"].tolist(), {"sampleRate": 48000, "fftSize": 1024, "sides": "two", "window": "blackman"}),
+        ([1, 2, 3, 4], {"sampleRate": 48000, "fftSize": 16}),
+        (np.zeros(64).tolist(), {"sampleRate": 48000}),
+        (rng.standard_normal(300).tolist(), {"window": "hamming"}),
+    ]
+    req = {"cases": [{"samples": s, "options": o} for s, o in cases]}
+    p = subprocess.run([node, os.path.join(root, "oracle", "pdsp_oracle.js"), "spectrum"], input=json.dumps(req),
+                       capture_output=True, text=True, timeout=120, check=True)
+    res = json.loads(p.stdout)["results"]
+    for (s, o), g in zip(cases, res):
+        w = oracle_mod.spectrum(s, sample_rate=o.get("sampleRate", 1), fft_size=o.get("fftSize"),
+                                window=o.get("window", "rect"), sides=o.get("sides", "one"))
+        assert np.array_equal(g["frequencies"], w["frequencies"])
+        assert np.abs(np.array(g["amplitude"]) - w["amplitude"]).max() <= 1e-13 * max(1.0, w["amplitude"].max())
+        assert g["peak"]["index"] == w["peak"]["index"] and abs(g["peak"]["amplitude"] - w["peak"]["amplitude"]) <= 1e-13
+    assert res[0]["peak"] == {"index": 2, "frequency": 12000, "amplitude": 1, "phase": -np.pi / 2}  # README.md:11
+    assert abs(res[3]["amplitude"][0] - 0.625) < 1e-15 and res[3]["peak"]["index"] == 1               # edge_cases.test.ts:180-197
+    assert not any(res[4]["amplitude"]) and res[4]["peak"]["index"] == 0
