@@ -474,8 +474,9 @@ int bigfft_out(const pdsp_plan *plan, long long batch, const T *b_re, const T *b
 }
 
 // One launch of tile_pass_kernel for a factor of 2^l points (tile width by factor: 64 / 32 / 32 / 16).
+// real_in: 0 = complex planes, 1 = real rows (in_im unused), 2 = real rows times the window table in in_im
 template <typename T, bool COLS>
-int tile_pass(int l, bool real_in, const T *in_re, const T *in_im, T *out_re, T *out_im,
+int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *out_im,
               const typename pdsp::vec2<T>::type *tw, const Tables<T> &t, pdsp::TileGeom g, T scale, long long batch,
               hipStream_t s) {
   const long long blocks = batch * g.nblk * g.tiles;
@@ -484,7 +485,10 @@ int tile_pass(int l, bool real_in, const T *in_re, const T *in_im, T *out_re, T 
   const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
 #define PDSP_TILE(L, TILE)                                                                                            \
   do {                                                                                                                \
-    if (COLS && real_in)                                                                                              \
+    if (COLS && real_in == 2)                                                                                         \
+      hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, COLS, COLS>), dim3((unsigned)blocks), dim3(256), 0, \
+                         s, in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch);                             \
+    else if (COLS && real_in)                                                                                         \
       hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, COLS>), dim3((unsigned)blocks), dim3(256), 0, s,    \
                          in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch);                                \
     else                                                                                                              \
@@ -507,30 +511,35 @@ constexpr int tile_width(int l) { return l == 6 ? 64 : (l == 9 ? 16 : 32); }
 // Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27 (not 2^18), f32, 16-byte aligned
 // planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
 // pass reads one pair and writes another, so input and output may alias each other.
+// `window` (real input only): applyWindow on the first pass's load; in_batch: distance between input rows.
 template <typename T>
 int tilepass_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out,
-                     T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s) {
+                     T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s, const T *window = nullptr,
+                     long long in_batch = 0) {
   const Tables<T> &t = tables<T>(plan);
   const long long n = plan->n;
+  if (in_batch == 0) in_batch = n;
+  const int first = im_in ? 0 : (window ? 2 : 1);
+  if (first == 2) im_in = window;  // the real first pass takes the window table through the unused plane argument
   if (t.tp_np == 2) {
     const long long a = 1LL << t.tp_l[0], b = 1LL << t.tp_l[1];
-    pdsp::TileGeom g1{n, 1, (int)(b / tile_width(t.tp_l[0])), 0, 0, b, b, 1u};
-    if (int rc = tile_pass<T, true>(t.tp_l[0], im_in == nullptr, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
+    pdsp::TileGeom g1{n, 1, (int)(b / tile_width(t.tp_l[0])), 0, 0, b, b, 1u, in_batch};
+    if (int rc = tile_pass<T, true>(t.tp_l[0], first, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
       return rc;
-    pdsp::TileGeom g2{n, 1, (int)(a / tile_width(t.tp_l[1])), 0, 0, 0, a, 1u};
-    return tile_pass<T, false>(t.tp_l[1], false, (const T *)s1_re, (const T *)s1_im, re_out, im_out, t.tp_tw[1], t, g2, scale,
+    pdsp::TileGeom g2{n, 1, (int)(a / tile_width(t.tp_l[1])), 0, 0, 0, a, 1u, n};
+    return tile_pass<T, false>(t.tp_l[1], 0, (const T *)s1_re, (const T *)s1_im, re_out, im_out, t.tp_tw[1], t, g2, scale,
                                batch, s);
   }
   const long long a = 1LL << t.tp_l[0], b = 1LL << t.tp_l[1], c = 1LL << t.tp_l[2];
-  pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(t.tp_l[0])), 0, 0, b * c, b * c, 1u};
-  if (int rc = tile_pass<T, true>(t.tp_l[0], im_in == nullptr, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
+  pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(t.tp_l[0])), 0, 0, b * c, b * c, 1u, in_batch};
+  if (int rc = tile_pass<T, true>(t.tp_l[0], first, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
     return rc;
-  pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(t.tp_l[1])), b * c, c, c, a * c, (unsigned)a};
-  if (int rc = tile_pass<T, true>(t.tp_l[1], false, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, t.tp_tw[1], t, g2, T(1),
+  pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(t.tp_l[1])), b * c, c, c, a * c, (unsigned)a, n};
+  if (int rc = tile_pass<T, true>(t.tp_l[1], 0, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, t.tp_tw[1], t, g2, T(1),
                                   batch, s))
     return rc;
-  pdsp::TileGeom g3{n, 1, (int)(a * b / tile_width(t.tp_l[2])), 0, 0, 0, a * b, 1u};
-  return tile_pass<T, false>(t.tp_l[2], false, (const T *)s2_re, (const T *)s2_im, re_out, im_out, t.tp_tw[2], t, g3, scale,
+  pdsp::TileGeom g3{n, 1, (int)(a * b / tile_width(t.tp_l[2])), 0, 0, 0, a * b, 1u, n};
+  return tile_pass<T, false>(t.tp_l[2], 0, (const T *)s2_re, (const T *)s2_im, re_out, im_out, t.tp_tw[2], t, g3, scale,
                              batch, s);
 }
 
@@ -1046,6 +1055,38 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     return PDSP_OK;
   }
   const T s_edge = T(1) / (T)n, s_mid = (sides == PDSP_SIDES_ONE ? T(2) : T(1)) / (T)n;
+  if constexpr (sizeof(T) == 4) {
+    // N >= 2^19, whole 16-byte aligned frames: three tile passes on (x*w, 0) (window on the first pass's
+    // load), then one element-wise pass to amplitude (+ phase) rows, where round 1's four-step makes five
+    // passes: 0.50-0.57 vs 0.40-0.43 TB/s algorithmic (tools/ab_long_spectrum.py).  Below 2^19 the
+    // four-step's three passes -- real first pass, amplitude fused into the last -- are the faster form
+    // (0.81-0.94 vs 0.72-0.82) and stay; so do partial / unaligned frames and f64.
+    if (t.log2n1 > 0 && t.tp_np == 3 && plan->log2n >= 19 && g_twopass && used == n && (frame_stride & 3) == 0 &&
+        (((uintptr_t)frames | (uintptr_t)window) & 15) == 0) {
+      T *amp = amp_out, *ph = phase_out;
+      const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins;
+      const size_t extra = (peaks_out && !amp ? rows : 0) + (peaks_out && !ph ? rows : 0);
+      StreamScratch mem(stream);
+      PDSP_HIP_TRY(mem.alloc((4 * plane + extra) * sizeof(T)));
+      T *const sc = (T *)mem.p;
+      if (peaks_out && !amp) amp = sc + 4 * plane;
+      if (peaks_out && !ph) ph = sc + 4 * plane + (amp_out ? 0 : rows);
+      // pass chain: frames -> s1 (-> s2) -> X; two passes: X = s2; three passes: X = s1 again
+      T *const s1_re = sc, *const s1_im = sc + plane, *const s2_re = sc + 2 * plane, *const s2_im = sc + 3 * plane;
+      T *const x_re = t.tp_np == 2 ? s2_re : s1_re, *const x_im = t.tp_np == 2 ? s2_im : s1_im;
+      if (int rc = tilepass_complex<T>(plan, batch, frames, (const T *)nullptr, x_re, x_im, T(1), s1_re, s1_im, s2_re, s2_im,
+                                       stream, window, frame_stride))
+        return rc;
+      const int nyq = (sides == PDSP_SIDES_ONE) ? (int)(n / 2) : -1;
+      hipLaunchKernelGGL((pdsp::amp_rows_kernel<T>), dim3(grid_for((long long)rows)), dim3(256), 0, stream, (const T *)x_re,
+                         (const T *)x_im, amp, ph, n, bins, nyq, s_edge, s_mid, (long long)rows);
+      PDSP_HIP_TRY(hipGetLastError());
+      if ((peaks_out || peak_idx_out) &&
+          launch_peaks<T>(amp, ph, bins, freq_scale, peak_idx_out, peaks_out, batch, stream) != hipSuccess)
+        return fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
+      return PDSP_OK;
+    }
+  }
   if (t.log2n1 > 0) {  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in the last pass
     const bool big = t.log2n1 > pdsp::kMaxLog2N1;  // general path: two scratch pairs
     T *amp = amp_out, *ph = phase_out;

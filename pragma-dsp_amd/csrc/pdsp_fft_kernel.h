@@ -1878,17 +1878,21 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
 // four rows, and four rows of LROW (a multiple of 8 for L >= 128) would land on the same banks.
 //   tw = radix table of the L-point transform; W_N^m = twa[m >> 9] * twb[m & 511].
 struct TileGeom {
-  long long n;          // N
+  long long n;          // N: distance between batch rows on the output side (and on the input side unless in_batch)
   int nblk, tiles;      // blocks per transform, tiles per block
   long long in_blk, out_blk, in_stride, out_stride;
   unsigned tmul;        // twiddle exponent multiplier (1, or A in the middle pass of three)
+  long long in_batch;   // distance between batch rows of the input (frames of spectrum(): the caller's stride)
 };
 
-template <typename T, int LOG2L, int TILE, bool COLS, bool REAL_IN = false>
+// REAL_IN: the first pass of Radix2Fft.forward / spectrum(): no imaginary plane; WINDOWED (with REAL_IN):
+// applyWindow on load, window value at the sample's index in the frame.
+template <typename T, int LOG2L, int TILE, bool COLS, bool REAL_IN = false, bool WINDOWED = false>
 __global__ void __launch_bounds__(256)
 tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
                  const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
                  const cx<T> *__restrict__ twb, const TileGeom g, const T scale, const long long batch) {
+  static_assert(!WINDOWED || (REAL_IN && COLS), "the window rides on the real first pass (in_im carries it)");
   using TR = FftTraits<LOG2L>;
   constexpr int L = TR::N, E = TR::E, TP = TR::TP, RPR = 256 / TP, ROUNDS = TILE / RPR;
   static_assert(LOG2L >= 6 && LOG2L <= 9 && TILE % RPR == 0 && TILE % 4 == 0 && ROUNDS >= 1, "tile of whole rounds");
@@ -1909,13 +1913,16 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
 
   if constexpr (COLS) {
     // strided tile in: element (p, j) -> LDS row j, position p
-    const size_t ibase = base + (size_t)blk * (size_t)g.in_blk + (size_t)(t0 + j4);
+    const size_t in_off = (size_t)blk * (size_t)g.in_blk + (size_t)(t0 + j4);  // index inside the frame
+    const size_t ibase = (size_t)b * (size_t)g.in_batch + in_off;
     static_for<L / SPI>([&](auto ic) {
       const int p = seg + SPI * ic;
       const size_t gi = ibase + (size_t)p * (size_t)g.in_stride;
-      const V4 r = ld_stream(reinterpret_cast<const V4 *>(in_re + gi));
+      V4 r = ld_stream(reinterpret_cast<const V4 *>(in_re + gi));
       V4 m = V4{T(0), T(0), T(0), T(0)};
       if constexpr (!REAL_IN) m = ld_stream(reinterpret_cast<const V4 *>(in_im + gi));
+      // WINDOWED: in_im is the window table (N values), indexed like the frame
+      if constexpr (WINDOWED) r = r * *reinterpret_cast<const V4 *>(in_im + in_off + (size_t)p * (size_t)g.in_stride);
       cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
       d[0 * LROWX] = cx<T>{r.x, m.x};
       d[1 * LROWX] = cx<T>{r.y, m.y};
@@ -1974,6 +1981,22 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
     st_stream(V4{v[0].x, v[1].x, v[2].x, v[3].x}, reinterpret_cast<V4 *>(out_re + go));
     st_stream(V4{v[0].y, v[1].y, v[2].y, v[3].y}, reinterpret_cast<V4 *>(out_im + go));
   });
+}
+
+// Amplitude (+ phase) rows of spectrum() from natural-order complex planes (the tail of the tile-pass
+// spectrum path): magnitude + scaleAmplitude{One,Two}Sided, spectrum.ts:45-72, :121-131.
+template <typename T>
+__global__ void __launch_bounds__(256)
+amp_rows_kernel(const T *__restrict__ re, const T *__restrict__ im, T *__restrict__ amp, T *__restrict__ ph,
+                const long long n, const int bins, const int nyq, const T s_edge, const T s_mid, const long long total) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const long long b = i / bins;
+    const int k = (int)(i - b * bins);
+    const cx<T> v{re[(size_t)b * (size_t)n + k], im[(size_t)b * (size_t)n + k]};
+    amp[i] = mag(v) * ((k == 0 || k == nyq) ? s_edge : s_mid);
+    if (ph) ph[i] = T(atan2(v.y, v.x));
+  }
 }
 
 // ---- general four-step path: N = N1 * N2 with 32 <= N1 <= N2 = the largest single-pass size ---

@@ -169,3 +169,50 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
             pdsp.lib.pdsp_set_twopass(prev)
         res[mode] = got
     assert rel_err(res[1], res[0]) <= 2e-6
+
+
+@pytest.mark.parametrize("log2n", [15, 17, 19, 21])
+def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
+    """spectrum() of frames longer than the single-pass limit (whole 16-byte aligned f32 frames).  From 2^19 up:
+    three tile passes on (x*w, 0) with the window on the first pass's load, then one pass to amplitude /
+    phase rows -- against round 1's four-step form (pdsp_set_twopass(0)) and the oracle, one- and two-sided,
+    with phase rows, peak indices and fused-peak records.  Below 2^19 (and for a partial, zero-padded frame
+    at any size) the four-step form runs either way; the same assertions hold."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 1 << log2n
+    tone = n // 37
+    rng = np.random.default_rng(200 + log2n)
+    t = np.arange(n)
+    x = (rng.standard_normal((3, n)) * 0.1 + np.sin(2 * np.pi * tone * t / n)).astype(np.float32)
+    plan = BatchedFft(n, "cuda:0")
+    dx = torch.from_numpy(x).cuda()
+    for window in ("rect", "hann"):
+        win = oracle_mod.create_window(window, n).astype(np.float32) if window != "rect" else None
+        for sides in ("one", "two"):
+            wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, two_sided=(sides == "two"),
+                                                               want_phase=True, want_peak=True)
+            res = {}
+            for mode in (1, 0):
+                prev = pdsp.lib.pdsp_set_twopass(mode)
+                try:
+                    amp, ph, pk = plan.spectrum(dx, window, sides, want_phase=True, want_peak=True)
+                    torch.cuda.synchronize()
+                finally:
+                    pdsp.lib.pdsp_set_twopass(prev)
+                a = amp.cpu().numpy()
+                assert a.shape == wamp.shape and rel_err(a, wamp) <= 1e-5
+                assert all(int(v) in (tone, n - tone if sides == "two" else tone) for v in pk.cpu())
+                mask = wamp > 1e-2 * wamp.max(axis=-1, keepdims=True)
+                d = np.abs((ph.cpu().numpy() - wph + np.pi) % (2 * np.pi) - np.pi)
+                assert d[mask].max() <= 2e-3
+                res[mode] = a
+            assert rel_err(res[1], res[0]) <= 2e-6
+    idx, freq, a, p, _, _ = plan.spectrum_peaks(dx, "hann", "one", 48000.0)
+    assert [int(v) for v in idx.cpu()] == [tone] * 3
+    short = torch.from_numpy(x[:, : n - 1000].copy()).cuda()          # zero-padded frames: four-step form
+    amp, _, _ = plan.spectrum(short, "hann", "one")
+    xs = x.copy()
+    xs[:, n - 1000:] = 0
+    wamp, _, _ = oracle_mod.Plan(n).spectrum_batch(xs, window=oracle_mod.create_window("hann", n).astype(np.float32))
+    assert rel_err(amp.cpu().numpy(), wamp) <= 1e-5
