@@ -14,8 +14,9 @@ and exits non-zero if any child failed.  The batch is split by rank with no data
 collective (weak scaling: 65,536 transforms per GPU, configs[4] at N=8 -- the batch idiom
 of bench/reallife/signals.ts:264-270 generalised), and the timed region is bracketed by
 a barrier + synchronize with the MAX over ranks taken.  Rank 0 prints ONE JSON line.
-`--gather` adds the one exchange step of the path, timed on its own: the
-RCCL all-gather of the output slabs and of the 16-byte-per-frame SpectrumPeak records.
+At N > 1 the one exchange step of the path follows the timed region and is timed
+on its own (`--no-gather` skips it): the RCCL all-gather of the output slabs and of the
+16-byte-per-frame SpectrumPeak records.
 
 Other workloads (parity-checked elsewhere; here for DESIGN.md's numbers):
   --workload spectrum16k   configs[3]: fused Hann+FFT+one-sided amplitude, N=16384,
@@ -357,7 +358,9 @@ def parse_args(argv):
     ap.add_argument("--ramp-seconds", type=float, default=0.6, help="untimed clock-ramp before the warm-up steps")
     ap.add_argument("--dist-backend", default=None, help="nccl (= RCCL, default) or gloo (default with --share-gpu / --dry-run)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of the output slabs and of the peak records")
+    ap.add_argument("--gather", action="store_true", help="(default at --gpus > 1; kept for older command lines)")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: skip the RCCL all-gather of the output slabs and of the peak records (timed on its own, after the timed region)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no compute: launcher + rendezvous + shard + gather + max-over-ranks only (CPU tests)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="testing the launcher: this rank exits with status 3")
@@ -577,7 +580,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         torch.cuda.synchronize(dev)
 
     gather = None
-    if args.gather and world > 1 and args.workload in ("fft4096", "real4096"):
+    if world > 1 and not args.no_gather and args.workload in ("fft4096", "real4096"):
         # The one exchange step of the path, timed on its own.  (i) the full output slabs:
         # at 2 GiB/rank the all-gather is xGMI-per-link bound and dwarfs the compute.  (ii) the reduced
         # output a consumer of spectrum() needs -- one 16-byte SpectrumPeak per frame (fused findPeak
@@ -599,15 +602,19 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         recs[:, 0] = pk_i
         recs[:, 1:] = torch.stack([pk_f, pk_a, pk_p], dim=1).view(torch.int32)
         torch.cuda.synchronize(dev)
-        if args.dist_backend != "nccl":
-            # gloo rehearsal (1-GPU box): the collective runs on host copies, 4096 rows of the slabs per
-            # rank -- it checks the plumbing; it is not a bandwidth figure
-            gather = {"slabs": timed_gather([ore[:4096].cpu(), oim[:4096].cpu()], 4096),
-                      "peaks_16B_per_frame": timed_gather([recs.cpu()], per_gpu),
-                      "note": "gloo rehearsal on host copies (slabs: 4096 rows per rank)"}
-        else:
-            gather = {"slabs": timed_gather([ore, oim], per_gpu),
-                      "peaks_16B_per_frame": timed_gather([recs], per_gpu)}
+        try:  # the value above is already measured: a failed exchange is reported, not fatal
+            if args.dist_backend != "nccl":
+                # gloo rehearsal (1-GPU box): the collective runs on host copies, 4096 rows of the slabs per
+                # rank -- it checks the plumbing; it is not a bandwidth figure
+                gather = {"slabs": timed_gather([ore[:4096].cpu(), oim[:4096].cpu()], 4096),
+                          "peaks_16B_per_frame": timed_gather([recs.cpu()], per_gpu),
+                          "note": "gloo rehearsal on host copies (slabs: 4096 rows per rank)"}
+            else:
+                # the small exchange first: it is the one a consumer of spectrum() needs
+                gather = {"peaks_16B_per_frame": timed_gather([recs], per_gpu)}
+                gather["slabs"] = timed_gather([ore, oim], per_gpu)
+        except Exception as exc:  # noqa: BLE001  (RuntimeError from RCCL / allocator)
+            gather = dict(gather or {}, error=f"{type(exc).__name__}: {exc}"[:300])
         gather["backend"] = args.dist_backend
 
     if rank == 0:

@@ -32,11 +32,9 @@ class PlanWindow:
     pointer, valid while the plan lives.  Passing it as `window` tells the engine which window it is,
     so the kernels that can fuse createWindow do (include/pdsp_hip.h); `.tensor()` gives a torch copy."""
 
-    def __init__(self, plan: "BatchedFft", kind: str):
-        out = C.c_void_p()
-        check(getattr(lib, "pdsp_plan_window_" + plan._sfx)(plan._h, _capi.WINDOW_TYPES[kind], C.byref(out)))
-        self._plan = plan  # keeps the owner alive
-        self._p = out.value
+    def __init__(self, plan: "BatchedFft", kind: str, ptr: int):
+        self._plan = plan  # keeps the owner alive (the plan caches pointers, not these objects: no cycle)
+        self._p = ptr
         self.kind = kind
         self.shape = (plan.size,)
         self.dtype = plan.dtype
@@ -103,12 +101,14 @@ class BatchedFft:
         """The plan's device copy of createWindow(kind, N), cached per kind like FourierLive's window
         cache (src/effect/index.ts:39-48).  A window named by kind is known to the engine (fused
         createWindow where a kernel supports it); a caller's own tensor is read as a table."""
-        w = self._windows.get(kind)
-        if w is None:
+        p = self._windows.get(kind)
+        if p is None:
             if kind not in _capi.WINDOW_TYPES:
                 raise PdspError(_capi.ERR_WINDOW_TYPE, f"Unsupported window type: {kind}")
-            w = self._windows[kind] = PlanWindow(self, kind)
-        return w
+            out = C.c_void_p()
+            check(getattr(lib, "pdsp_plan_window_" + self._sfx)(self._h, _capi.WINDOW_TYPES[kind], C.byref(out)))
+            p = self._windows[kind] = out.value
+        return PlanWindow(self, kind, p)
 
     # -- transforms ------------------------------------------------------------
     def forward(self, re: torch.Tensor, im: torch.Tensor | None = None, out=None):
