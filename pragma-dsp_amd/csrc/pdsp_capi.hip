@@ -114,6 +114,11 @@ struct Tables {
   int tp_np = 0;
   int tp_l[3] = {0, 0, 0};
   T2 *tp_tw[3] = {nullptr, nullptr, nullptr};
+  // the same for the N/2-point transform of the packed-real spectrum path (2^15 <= N <= 2^27): it runs on
+  // this plan's twa / twb with doubled exponents (TileGeom::tshift)
+  int hp_np = 0;
+  int hp_l[3] = {0, 0, 0};
+  T2 *hp_tw[3] = {nullptr, nullptr, nullptr};
   void release() {
     if (tw12) (void)hipFree(tw12);
     tw12 = nullptr;
@@ -130,6 +135,11 @@ struct Tables {
       q = nullptr;
     }
     tp_np = 0;
+    for (T2 *&q : hp_tw) {
+      if (q) (void)hipFree(q);
+      q = nullptr;
+    }
+    hp_np = 0;
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
     if (tw1) (void)hipFree(tw1);
@@ -474,7 +484,8 @@ int bigfft_out(const pdsp_plan *plan, long long batch, const T *b_re, const T *b
 }
 
 // One launch of tile_pass_kernel for a factor of 2^l points (tile width by factor: 64 / 32 / 32 / 16).
-// real_in: 0 = complex planes, 1 = real rows (in_im unused), 2 = real rows times the window table in in_im
+// real_in = tile_pass_kernel's IN: 0 complex planes, 1 real rows (in_im unused), 2 real rows times the window table
+// in in_im, 3 / 4 the same for packed real rows (two samples per point)
 template <typename T, bool COLS>
 int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *out_im,
               const typename pdsp::vec2<T>::type *tw, const Tables<T> &t, pdsp::TileGeom g, T scale, long long batch,
@@ -483,17 +494,18 @@ int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *
   if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
   const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
   const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
-#define PDSP_TILE(L, TILE)                                                                                            \
-  do {                                                                                                                \
-    if (COLS && real_in == 2)                                                                                         \
-      hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, COLS, COLS>), dim3((unsigned)blocks), dim3(256), 0, \
-                         s, in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch);                             \
-    else if (COLS && real_in)                                                                                         \
-      hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, COLS>), dim3((unsigned)blocks), dim3(256), 0, s,    \
-                         in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch);                                \
-    else                                                                                                              \
-      hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, false>), dim3((unsigned)blocks), dim3(256), 0, s,   \
-                         in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch);                                \
+#define PDSP_TILE_IN(L, TILE, IN)                                                                                  \
+  hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, (COLS ? IN : 0)>), dim3((unsigned)blocks), dim3(256), \
+                     0, s, in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch)
+#define PDSP_TILE(L, TILE)                                 \
+  do {                                                     \
+    switch (COLS ? real_in : 0) {                          \
+      case 1: PDSP_TILE_IN(L, TILE, 1); break;             \
+      case 2: PDSP_TILE_IN(L, TILE, 2); break;             \
+      case 3: PDSP_TILE_IN(L, TILE, 3); break;             \
+      case 4: PDSP_TILE_IN(L, TILE, 4); break;             \
+      default: PDSP_TILE_IN(L, TILE, 0); break;            \
+    }                                                      \
   } while (0)
   switch (l) {
     case 6: PDSP_TILE(6, 64); break;
@@ -503,10 +515,40 @@ int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *
     default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported tile-pass factor 2^%d", l);
   }
 #undef PDSP_TILE
+#undef PDSP_TILE_IN
   PDSP_HIP_TRY(hipGetLastError());
   return PDSP_OK;
 }
 constexpr int tile_width(int l) { return l == 6 ? 64 : (l == 9 ? 16 : 32); }
+
+// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27 (not 2^18), f32, 16-byte aligned
+// planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
+// pass reads one pair and writes another, so input and output may alias each other.
+// `window` (real input only): applyWindow on the first pass's load; in_batch: distance between input rows.
+// The pass chain on one set of factor tables: `n` points per transform, np factors 2^l[i] with radix tables tw[i];
+// tshift = 1 when t.twa / t.twb belong to the 2n-point plan.  `first` = tile_pass_kernel's IN for the first pass
+// (im_in then carries the window table or nothing); in_batch = distance between input rows (real samples for
+// first >= 1).
+template <typename T>
+int tilepass_chain(const Tables<T> &t, long long n, int np, const int *l, typename pdsp::vec2<T>::type *const *tw,
+                   unsigned tshift, int first, long long batch, const T *re_in, const T *im_in, long long in_batch,
+                   T *re_out, T *im_out, T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s) {
+  if (np == 2) {
+    const long long a = 1LL << l[0], b = 1LL << l[1];
+    pdsp::TileGeom g1{n, 1, (int)(b / tile_width(l[0])), 0, 0, b, b, 1u, in_batch, tshift};
+    if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
+    pdsp::TileGeom g2{n, 1, (int)(a / tile_width(l[1])), 0, 0, 0, a, 1u, n, tshift};
+    return tile_pass<T, false>(l[1], 0, (const T *)s1_re, (const T *)s1_im, re_out, im_out, tw[1], t, g2, scale, batch, s);
+  }
+  const long long a = 1LL << l[0], b = 1LL << l[1], c = 1LL << l[2];
+  pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(l[0])), 0, 0, b * c, b * c, 1u, in_batch, tshift};
+  if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
+  pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(l[1])), b * c, c, c, a * c, (unsigned)a, n, tshift};
+  if (int rc = tile_pass<T, true>(l[1], 0, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, tw[1], t, g2, T(1), batch, s))
+    return rc;
+  pdsp::TileGeom g3{n, 1, (int)(a * b / tile_width(l[2])), 0, 0, 0, a * b, 1u, n, tshift};
+  return tile_pass<T, false>(l[2], 0, (const T *)s2_re, (const T *)s2_im, re_out, im_out, tw[2], t, g3, scale, batch, s);
+}
 
 // Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27 (not 2^18), f32, 16-byte aligned
 // planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
@@ -517,30 +559,9 @@ int tilepass_complex(const pdsp_plan *plan, long long batch, const T *re_in, con
                      T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s, const T *window = nullptr,
                      long long in_batch = 0) {
   const Tables<T> &t = tables<T>(plan);
-  const long long n = plan->n;
-  if (in_batch == 0) in_batch = n;
   const int first = im_in ? 0 : (window ? 2 : 1);
-  if (first == 2) im_in = window;  // the real first pass takes the window table through the unused plane argument
-  if (t.tp_np == 2) {
-    const long long a = 1LL << t.tp_l[0], b = 1LL << t.tp_l[1];
-    pdsp::TileGeom g1{n, 1, (int)(b / tile_width(t.tp_l[0])), 0, 0, b, b, 1u, in_batch};
-    if (int rc = tile_pass<T, true>(t.tp_l[0], first, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
-      return rc;
-    pdsp::TileGeom g2{n, 1, (int)(a / tile_width(t.tp_l[1])), 0, 0, 0, a, 1u, n};
-    return tile_pass<T, false>(t.tp_l[1], 0, (const T *)s1_re, (const T *)s1_im, re_out, im_out, t.tp_tw[1], t, g2, scale,
-                               batch, s);
-  }
-  const long long a = 1LL << t.tp_l[0], b = 1LL << t.tp_l[1], c = 1LL << t.tp_l[2];
-  pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(t.tp_l[0])), 0, 0, b * c, b * c, 1u, in_batch};
-  if (int rc = tile_pass<T, true>(t.tp_l[0], first, re_in, im_in, s1_re, s1_im, t.tp_tw[0], t, g1, T(1), batch, s))
-    return rc;
-  pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(t.tp_l[1])), b * c, c, c, a * c, (unsigned)a, n};
-  if (int rc = tile_pass<T, true>(t.tp_l[1], 0, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, t.tp_tw[1], t, g2, T(1),
-                                  batch, s))
-    return rc;
-  pdsp::TileGeom g3{n, 1, (int)(a * b / tile_width(t.tp_l[2])), 0, 0, 0, a * b, 1u, n};
-  return tile_pass<T, false>(t.tp_l[2], 0, (const T *)s2_re, (const T *)s2_im, re_out, im_out, t.tp_tw[2], t, g3, scale,
-                             batch, s);
+  return tilepass_chain<T>(t, plan->n, t.tp_np, t.tp_l, t.tp_tw, 0u, first, batch, re_in, first == 2 ? window : im_in,
+                           in_batch ? in_batch : plan->n, re_out, im_out, scale, s1_re, s1_im, s2_re, s2_im, s);
 }
 
 template <typename T>
@@ -927,6 +948,20 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
           e = hipMalloc((void **)&t.tp_tw[i], tf.size() * sizeof(T2));
           if (e == hipSuccess) e = hipMemcpy(t.tp_tw[i], tf.data(), tf.size() * sizeof(T2), hipMemcpyHostToDevice);
         }
+        // the N/2-point transform of the packed-real spectrum path: 2^14 ... 2^17 in two factors, above in three
+        const int lm = log2n - 1;
+        if (lm <= 17) {
+          t.hp_np = 2;
+          t.hp_l[0] = lm / 2, t.hp_l[1] = lm - t.hp_l[0];
+        } else {
+          t.hp_np = 3;
+          t.hp_l[0] = lm / 3, t.hp_l[1] = (lm - t.hp_l[0]) / 2, t.hp_l[2] = lm - t.hp_l[0] - t.hp_l[1];
+        }
+        for (int i = 0; i < t.hp_np && e == hipSuccess; ++i) {
+          const std::vector<T2> tf = build_twiddles<T2>(t.hp_l[i]);
+          e = hipMalloc((void **)&t.hp_tw[i], tf.size() * sizeof(T2));
+          if (e == hipSuccess) e = hipMemcpy(t.hp_tw[i], tf.data(), tf.size() * sizeof(T2), hipMemcpyHostToDevice);
+        }
       }
       if (e == hipSuccess && t.log2n1 > pdsp::kMaxLog2N1) {
         const std::vector<T2> t1 = build_twiddles<T2>(t.log2n1);
@@ -1056,30 +1091,34 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
   }
   const T s_edge = T(1) / (T)n, s_mid = (sides == PDSP_SIDES_ONE ? T(2) : T(1)) / (T)n;
   if constexpr (sizeof(T) == 4) {
-    // N >= 2^19, whole 16-byte aligned frames: three tile passes on (x*w, 0) (window on the first pass's
-    // load), then one element-wise pass to amplitude (+ phase) rows, where round 1's four-step makes five
-    // passes: 0.50-0.57 vs 0.40-0.43 TB/s algorithmic (tools/ab_long_spectrum.py).  Below 2^19 the
-    // four-step's three passes -- real first pass, amplitude fused into the last -- are the faster form
-    // (0.81-0.94 vs 0.72-0.82) and stay; so do partial / unaligned frames and f64.
-    if (t.log2n1 > 0 && t.tp_np == 3 && plan->log2n >= 19 && g_twopass && used == n && (frame_stride & 3) == 0 &&
+    // N beyond the single-pass limit, whole 16-byte aligned frames: the packed-real form on tile passes.
+    // z[m] = (x*w)[2m] + i (x*w)[2m+1] is read straight from the frame (and the window table) by the first
+    // pass; two (N <= 2^18) or three passes of the N/2-point transform; split_amp_rows_kernel undoes the
+    // packing on the way to the amplitude (+ phase) rows.  HBM bytes per sample: 4+4, 4+4 (, 4+4), 4+2 = 22
+    // (30) where the four-step forms on (x*w, 0) move 38 (70).  The four-step forms stay for partial /
+    // unaligned frames and f64.
+    if (t.log2n1 > 0 && t.hp_np && g_twopass && used == n && (frame_stride & 3) == 0 &&
         (((uintptr_t)frames | (uintptr_t)window) & 15) == 0) {
       T *amp = amp_out, *ph = phase_out;
-      const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins;
+      const long long m = n / 2;
+      const size_t plane = (size_t)batch * (size_t)m, rows = (size_t)batch * bins;
       const size_t extra = (peaks_out && !amp ? rows : 0) + (peaks_out && !ph ? rows : 0);
       StreamScratch mem(stream);
       PDSP_HIP_TRY(mem.alloc((4 * plane + extra) * sizeof(T)));
       T *const sc = (T *)mem.p;
       if (peaks_out && !amp) amp = sc + 4 * plane;
       if (peaks_out && !ph) ph = sc + 4 * plane + (amp_out ? 0 : rows);
-      // pass chain: frames -> s1 (-> s2) -> X; two passes: X = s2; three passes: X = s1 again
+      // pass chain: frames -> s1 (-> s2) -> Z; two passes: Z = s2; three passes: Z = s1 again
       T *const s1_re = sc, *const s1_im = sc + plane, *const s2_re = sc + 2 * plane, *const s2_im = sc + 3 * plane;
-      T *const x_re = t.tp_np == 2 ? s2_re : s1_re, *const x_im = t.tp_np == 2 ? s2_im : s1_im;
-      if (int rc = tilepass_complex<T>(plan, batch, frames, (const T *)nullptr, x_re, x_im, T(1), s1_re, s1_im, s2_re, s2_im,
-                                       stream, window, frame_stride))
+      T *const z_re = t.hp_np == 2 ? s2_re : s1_re, *const z_im = t.hp_np == 2 ? s2_im : s1_im;
+      if (int rc = tilepass_chain<T>(t, m, t.hp_np, t.hp_l, t.hp_tw, 1u, window ? 4 : 3, batch, frames, window,
+                                     frame_stride, z_re, z_im, T(1), s1_re, s1_im, s2_re, s2_im, stream))
         return rc;
-      const int nyq = (sides == PDSP_SIDES_ONE) ? (int)(n / 2) : -1;
-      hipLaunchKernelGGL((pdsp::amp_rows_kernel<T>), dim3(grid_for((long long)rows)), dim3(256), 0, stream, (const T *)x_re,
-                         (const T *)x_im, amp, ph, n, bins, nyq, s_edge, s_mid, (long long)rows);
+      const long long chunks = (m / 2 + 1 + 1023) / 1024;
+      if (batch * chunks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
+      hipLaunchKernelGGL((pdsp::split_amp_rows_kernel<T>), dim3((unsigned)(batch * chunks)), dim3(256), 0, stream,
+                         (const T *)z_re, (const T *)z_im, amp, ph, reinterpret_cast<const pdsp::cx<T> *>(t.twa),
+                         reinterpret_cast<const pdsp::cx<T> *>(t.twb), (int)m, bins, s_edge, s_mid, batch);
       PDSP_HIP_TRY(hipGetLastError());
       if ((peaks_out || peak_idx_out) &&
           launch_peaks<T>(amp, ph, bins, freq_scale, peak_idx_out, peaks_out, batch, stream) != hipSuccess)

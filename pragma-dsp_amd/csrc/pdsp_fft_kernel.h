@@ -1882,17 +1882,26 @@ struct TileGeom {
   int nblk, tiles;      // blocks per transform, tiles per block
   long long in_blk, out_blk, in_stride, out_stride;
   unsigned tmul;        // twiddle exponent multiplier (1, or A in the middle pass of three)
-  long long in_batch;   // distance between batch rows of the input (frames of spectrum(): the caller's stride)
+  long long in_batch;   // distance between batch rows of the input (frames of spectrum(): the caller's stride,
+                        // in real samples)
+  unsigned tshift;      // 0, or 1 when twa / twb belong to a plan of 2N points (W_N^m = W_2N^(2m): the
+                        // N/2-point transform of the packed-real spectrum path on its N-point plan's tables)
 };
 
-// REAL_IN: the first pass of Radix2Fft.forward / spectrum(): no imaginary plane; WINDOWED (with REAL_IN):
-// applyWindow on load, window value at the sample's index in the frame.
-template <typename T, int LOG2L, int TILE, bool COLS, bool REAL_IN = false, bool WINDOWED = false>
+// IN (first pass only; in_im then carries the window table or nothing):
+//   0  complex planes
+//   1  real rows: the first pass of Radix2Fft.forward / spectrum(), no imaginary plane
+//   2  real rows times the window table (applyWindow on load, window value at the sample's index in the frame)
+//   3  PACKED real rows: point m of the N-point transform is (x[2m], x[2m+1]) of a 2N-sample frame -- the
+//      packed-real form of spectrum() (split_amp_rows_kernel undoes the packing)
+//   4  packed real rows times the window table
+template <typename T, int LOG2L, int TILE, bool COLS, int IN = 0>
 __global__ void __launch_bounds__(256)
 tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
                  const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
                  const cx<T> *__restrict__ twb, const TileGeom g, const T scale, const long long batch) {
-  static_assert(!WINDOWED || (REAL_IN && COLS), "the window rides on the real first pass (in_im carries it)");
+  static_assert(IN == 0 || COLS, "real / packed / windowed input rides on the first (column) pass");
+  constexpr bool REAL_IN = IN == 1 || IN == 2, WINDOWED = IN == 2 || IN == 4, PACKED = IN >= 3;
   using TR = FftTraits<LOG2L>;
   constexpr int L = TR::N, E = TR::E, TP = TR::TP, RPR = 256 / TP, ROUNDS = TILE / RPR;
   static_assert(LOG2L >= 6 && LOG2L <= 9 && TILE % RPR == 0 && TILE % 4 == 0 && ROUNDS >= 1, "tile of whole rounds");
@@ -1917,6 +1926,22 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
     const size_t ibase = (size_t)b * (size_t)g.in_batch + in_off;
     static_for<L / SPI>([&](auto ic) {
       const int p = seg + SPI * ic;
+      if constexpr (PACKED) {
+        // four points = eight consecutive samples of the frame (32 bytes per lane, TILE * 8 per segment)
+        const size_t fo = 2 * (in_off + (size_t)p * (size_t)g.in_stride);  // sample index inside the frame
+        const T *const src = in_re + (size_t)b * (size_t)g.in_batch + fo;
+        V4 r0 = ld_stream(reinterpret_cast<const V4 *>(src)), r1 = ld_stream(reinterpret_cast<const V4 *>(src) + 1);
+        if constexpr (WINDOWED) {
+          r0 = r0 * *reinterpret_cast<const V4 *>(in_im + fo);
+          r1 = r1 * *(reinterpret_cast<const V4 *>(in_im + fo) + 1);
+        }
+        cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
+        d[0 * LROWX] = cx<T>{r0.x, r0.y};
+        d[1 * LROWX] = cx<T>{r0.z, r0.w};
+        d[2 * LROWX] = cx<T>{r1.x, r1.y};
+        d[3 * LROWX] = cx<T>{r1.z, r1.w};
+        return;
+      }
       const size_t gi = ibase + (size_t)p * (size_t)g.in_stride;
       V4 r = ld_stream(reinterpret_cast<const V4 *>(in_re + gi));
       V4 m = V4{T(0), T(0), T(0), T(0)};
@@ -1965,7 +1990,7 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
     cx<T> v[4] = {d[0 * LROWX], d[1 * LROWX], d[2 * LROWX], d[3 * LROWX]};
     if constexpr (COLS) {
       // W_N^(tmul (t0 + j4 + j) p), j = 0..3: one two-level lookup for j = 0, then steps of W_N^(tmul p)
-      const unsigned mp = g.tmul * (unsigned)p;                 // < N
+      const unsigned mp = (g.tmul * (unsigned)p) << g.tshift;   // < N (of the tables' plan)
       const unsigned m = mp * (unsigned)(t0 + j4);              // < N <= 2^27
       cx<T> w = cmul(twa[m >> 9], twb[m & 511]);
       const cx<T> ws = cmul(twa[mp >> 9], twb[mp & 511]);
@@ -1983,20 +2008,59 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
   });
 }
 
-// Amplitude (+ phase) rows of spectrum() from natural-order complex planes (the tail of the tile-pass
-// spectrum path): magnitude + scaleAmplitude{One,Two}Sided, spectrum.ts:45-72, :121-131.
+// The tail of the packed-real long-frame spectrum path: Z = the M-point transform (natural order, planar)
+// of z[m] = x[2m] + i x[2m+1], M = N/2.  One lane takes the pair (k, M - k), 0 <= k <= M/2:
+//   X[k]     =      (Z[k] + conj(Z[M-k])) / 2 - i W_N^k (Z[k] - conj(Z[M-k])) / 2
+//   X[M - k] = conj((Z[k] + conj(Z[M-k])) / 2 + i W_N^k (Z[k] - conj(Z[M-k])) / 2),   Z[M] = Z[0]
+// -- the same split spectrum_packed_kernel runs from LDS -- then magnitude + scaleAmplitude{One,Two}Sided
+// (+ phase), spectrum.ts:45-72, :121-131; two-sided rows get X[N - k] = conj(X[k]) as well.
+//   W_N^k = twa[k >> 9] * twb[k & 511] (the N-point plan's two-level table); bins = M + 1 or N.
 template <typename T>
 __global__ void __launch_bounds__(256)
-amp_rows_kernel(const T *__restrict__ re, const T *__restrict__ im, T *__restrict__ amp, T *__restrict__ ph,
-                const long long n, const int bins, const int nyq, const T s_edge, const T s_mid, const long long total) {
-  const long long step = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-    const long long b = i / bins;
-    const int k = (int)(i - b * bins);
-    const cx<T> v{re[(size_t)b * (size_t)n + k], im[(size_t)b * (size_t)n + k]};
-    amp[i] = mag(v) * ((k == 0 || k == nyq) ? s_edge : s_mid);
-    if (ph) ph[i] = T(atan2(v.y, v.x));
-  }
+split_amp_rows_kernel(const T *__restrict__ zre, const T *__restrict__ zim, T *__restrict__ amp, T *__restrict__ ph,
+                      const cx<T> *__restrict__ twa, const cx<T> *__restrict__ twb, const int M, const int bins,
+                      const T s_edge, const T s_mid, const long long batch) {
+  const int per = M / 2 + 1;                       // pairs per frame
+  const int chunks = (per + 1023) / 1024;          // 1024 pairs per workgroup: four per lane, 256 apart
+  const long long b = (long long)blockIdx.x / chunks;
+  const int c0 = (int)((long long)blockIdx.x % chunks) * 1024 + (int)threadIdx.x;
+  if (b >= batch) return;
+  const T *const re = zre + (size_t)b * (size_t)M, *const im = zim + (size_t)b * (size_t)M;
+  T *const arow = amp + (size_t)b * (size_t)bins;
+  T *const prow = ph ? ph + (size_t)b * (size_t)bins : nullptr;
+  const bool two = bins > M + 1;
+  cx<T> z[4], zp[4];
+  static_for<4>([&](auto q) {
+    const int k = c0 + 256 * q, kc = k < per ? k : per - 1;  // unconditional clamped loads
+    const int km = (M - kc) & (M - 1);
+    z[q] = cx<T>{ld_stream(re + kc), ld_stream(im + kc)};
+    zp[q] = cx<T>{ld_stream(re + km), ld_stream(im + km)};
+  });
+  static_for<4>([&](auto q) {
+    const int k = c0 + 256 * q;
+    if (k < per) {
+      const cx<T> w = cmul(twa[k >> 9], twb[k & 511]);
+      const cx<T> e = (z[q] + conj(zp[q])) * T(0.5), p = cmul(z[q] - conj(zp[q]), w) * T(0.5);
+      const cx<T> xa = add_mul_neg_i(e, p), xb = conj(add_mul_pos_i(e, p));  // X[k], X[M - k]
+      const T sc = k == 0 ? s_edge : s_mid;  // k = 0 <-> bins 0 and M: DC and Nyquist
+      const T ma = mag(xa) * sc, mb = mag(xb) * sc;
+      const int k2 = M - k;
+      arow[k] = ma;
+      arow[k2] = mb;  // k = M/2: the same bin, the same value
+      if (prow) {
+        prow[k] = T(atan2(xa.y, xa.x));
+        prow[k2] = T(atan2(xb.y, xb.x));
+      }
+      if (two && k > 0) {  // X[N - k] = conj(X[k]), X[N - (M - k)] = X[M + k] = conj(X[M - k])
+        arow[2 * M - k] = ma;
+        arow[M + k] = mb;
+        if (prow) {
+          prow[2 * M - k] = T(atan2(-xa.y, xa.x));
+          prow[M + k] = T(atan2(-xb.y, xb.x));
+        }
+      }
+    }
+  });
 }
 
 // ---- general four-step path: N = N1 * N2 with 32 <= N1 <= N2 = the largest single-pass size ---

@@ -171,13 +171,13 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
     assert rel_err(res[1], res[0]) <= 2e-6
 
 
-@pytest.mark.parametrize("log2n", [15, 17, 19, 21])
+@pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20, 21, 22, 24])
 def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
-    """spectrum() of frames longer than the single-pass limit (whole 16-byte aligned f32 frames).  From 2^19 up:
-    three tile passes on (x*w, 0) with the window on the first pass's load, then one pass to amplitude /
-    phase rows -- against round 1's four-step form (pdsp_set_twopass(0)) and the oracle, one- and two-sided,
-    with phase rows, peak indices and fused-peak records.  Below 2^19 (and for a partial, zero-padded frame
-    at any size) the four-step form runs either way; the same assertions hold."""
+    """spectrum() of frames longer than the single-pass limit (whole 16-byte aligned f32 frames): the packed-real
+    form on tile passes -- the N/2-point transform of (x*w)[2m] + i (x*w)[2m+1] read straight from the frame,
+    then split_amp_rows_kernel -- against round 1's four-step form on (x*w, 0) (pdsp_set_twopass(0)) and the
+    oracle, one- and two-sided, with phase rows, peak indices and fused-peak records.  A partial (zero-padded)
+    frame takes the four-step form either way; the same assertions hold."""
     import torch
     from pragma_dsp_amd.batch import BatchedFft
     n = 1 << log2n
