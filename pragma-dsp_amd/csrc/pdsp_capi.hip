@@ -119,6 +119,8 @@ struct Tables {
   int hp_np = 0;
   int hp_l[3] = {0, 0, 0};
   T2 *hp_tw[3] = {nullptr, nullptr, nullptr};
+  float *hp_win = nullptr;  // angle-addition tables of the fused cosine-sum windows (TileGeom::wa ...): wa | wb | wstep | we
+  size_t hp_win_a = 0;      // entries (cos, sin pairs) of wa
   void release() {
     if (tw12) (void)hipFree(tw12);
     tw12 = nullptr;
@@ -140,6 +142,8 @@ struct Tables {
       q = nullptr;
     }
     hp_np = 0;
+    if (hp_win) (void)hipFree(hp_win);
+    hp_win = nullptr;
     if (twa) (void)hipFree(twa);
     if (twb) (void)hipFree(twb);
     if (tw1) (void)hipFree(tw1);
@@ -495,7 +499,8 @@ int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *
   const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
   const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
 #define PDSP_TILE_IN(L, TILE, IN)                                                                                  \
-  hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, (COLS ? IN : 0)>), dim3((unsigned)blocks), dim3(256), \
+  hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, ((COLS && (IN < 5 || sizeof(T) == 4)) ? IN : 0)>),    \
+                     dim3((unsigned)blocks), dim3(256),                                                               \
                      0, s, in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch)
 #define PDSP_TILE(L, TILE)                                 \
   do {                                                     \
@@ -504,6 +509,8 @@ int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *
       case 2: PDSP_TILE_IN(L, TILE, 2); break;             \
       case 3: PDSP_TILE_IN(L, TILE, 3); break;             \
       case 4: PDSP_TILE_IN(L, TILE, 4); break;             \
+      case 5: PDSP_TILE_IN(L, TILE, 5); break;             \
+      case 6: PDSP_TILE_IN(L, TILE, 6); break;             \
       default: PDSP_TILE_IN(L, TILE, 0); break;            \
     }                                                      \
   } while (0)
@@ -532,16 +539,25 @@ constexpr int tile_width(int l) { return l == 6 ? 64 : (l == 9 ? 16 : 32); }
 template <typename T>
 int tilepass_chain(const Tables<T> &t, long long n, int np, const int *l, typename pdsp::vec2<T>::type *const *tw,
                    unsigned tshift, int first, long long batch, const T *re_in, const T *im_in, long long in_batch,
-                   T *re_out, T *im_out, T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s) {
+                   T *re_out, T *im_out, T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s,
+                   const pdsp::TileGeom *fused_win = nullptr) {
+  auto with_window = [&](pdsp::TileGeom &g) {  // first = 5 / 6: the angle-addition tables and coefficients
+    if (fused_win) {
+      g.wa = fused_win->wa, g.wb = fused_win->wb, g.wstep = fused_win->wstep, g.we = fused_win->we;
+      g.k0 = fused_win->k0, g.k1 = fused_win->k1, g.k2 = fused_win->k2;
+    }
+  };
   if (np == 2) {
     const long long a = 1LL << l[0], b = 1LL << l[1];
     pdsp::TileGeom g1{n, 1, (int)(b / tile_width(l[0])), 0, 0, b, b, 1u, in_batch, tshift};
+    with_window(g1);
     if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
     pdsp::TileGeom g2{n, 1, (int)(a / tile_width(l[1])), 0, 0, 0, a, 1u, n, tshift};
     return tile_pass<T, false>(l[1], 0, (const T *)s1_re, (const T *)s1_im, re_out, im_out, tw[1], t, g2, scale, batch, s);
   }
   const long long a = 1LL << l[0], b = 1LL << l[1], c = 1LL << l[2];
   pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(l[0])), 0, 0, b * c, b * c, 1u, in_batch, tshift};
+  with_window(g1);
   if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
   pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(l[1])), b * c, c, c, a * c, (unsigned)a, n, tshift};
   if (int rc = tile_pass<T, true>(l[1], 0, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, tw[1], t, g2, T(1), batch, s))
@@ -962,6 +978,27 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
           e = hipMalloc((void **)&t.hp_tw[i], tf.size() * sizeof(T2));
           if (e == hipSuccess) e = hipMemcpy(t.hp_tw[i], tf.data(), tf.size() * sizeof(T2), hipMemcpyHostToDevice);
         }
+        if (e == hipSuccess) {
+          // fused createWindow on the packed first pass (tile_pass_kernel IN = 5 / 6; fourier.ts:14-52:
+          // f = 2 pi / (size - 1)): cs(f n) by angle addition, tables built in f64
+          const double f = 2.0 * M_PI / (double)(size - 1);
+          const long long in_stride = (size / 2) >> t.hp_l[0];              // points between the rows of a column
+          const int spi = 1024 / tile_width(t.hp_l[0]);                     // tile_pass_kernel's SPI
+          t.hp_win_a = (size_t)((size / 8 + 511) / 512);
+          std::vector<float> w(2 * (t.hp_win_a + 512 + 8 + 8 + 16));  // + wq (fft_split4_kernel's packed loader, N = 2^15)
+          size_t o = 0;
+          for (size_t i = 0; i < t.hp_win_a; ++i, o += 2)
+            w[o] = (float)std::cos(f * 4096.0 * (double)i), w[o + 1] = (float)std::sin(f * 4096.0 * (double)i);
+          for (int j = 0; j < 512; ++j, o += 2) w[o] = (float)std::cos(f * 8.0 * j), w[o + 1] = (float)std::sin(f * 8.0 * j);
+          for (int ic = 0; ic < 8; ++ic, o += 2) {
+            const double a = f * 2.0 * (double)in_stride * (double)spi * (double)ic;
+            w[o] = (float)std::cos(a), w[o + 1] = (float)std::sin(a);
+          }
+          for (int ee = 0; ee < 8; ++ee, o += 2) w[o] = (float)std::cos(f * ee), w[o + 1] = (float)std::sin(f * ee);
+          for (int q = 0; q < 16; ++q, o += 2) w[o] = (float)std::cos(f * 2048.0 * q), w[o + 1] = (float)std::sin(f * 2048.0 * q);
+          e = hipMalloc((void **)&t.hp_win, w.size() * sizeof(float));
+          if (e == hipSuccess) e = hipMemcpy(t.hp_win, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+        }
       }
       if (e == hipSuccess && t.log2n1 > pdsp::kMaxLog2N1) {
         const std::vector<T2> t1 = build_twiddles<T2>(t.log2n1);
@@ -1093,9 +1130,9 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
   if constexpr (sizeof(T) == 4) {
     // N beyond the single-pass limit, whole 16-byte aligned frames: the packed-real form on tile passes.
     // z[m] = (x*w)[2m] + i (x*w)[2m+1] is read straight from the frame (and the window table) by the first
-    // pass; two (N <= 2^18) or three passes of the N/2-point transform; split_amp_rows_kernel undoes the
-    // packing on the way to the amplitude (+ phase) rows.  HBM bytes per sample: 4+4, 4+4 (, 4+4), 4+2 = 22
-    // (30) where the four-step forms on (x*w, 0) move 38 (70).  The four-step forms stay for partial /
+    // pass; two (N <= 2^18) or three passes of the N/2-point transform (one pass of fft_split4_kernel at
+    // N = 2^15); split_amp_rows_kernel undoes the packing on the way to the amplitude (+ phase) rows.  HBM
+    // bytes per sample: 4+4, 4+4 (, 4+4), 4+2 = 22 (30) where the four-step forms on (x*w, 0) move 38 (70).  The four-step forms stay for partial /
     // unaligned frames and f64.
     if (t.log2n1 > 0 && t.hp_np && g_twopass && used == n && (frame_stride & 3) == 0 &&
         (((uintptr_t)frames | (uintptr_t)window) & 15) == 0) {
@@ -1111,10 +1148,45 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       // pass chain: frames -> s1 (-> s2) -> Z; two passes: Z = s2; three passes: Z = s1 again
       T *const s1_re = sc, *const s1_im = sc + plane, *const s2_re = sc + 2 * plane, *const s2_im = sc + 3 * plane;
       T *const z_re = t.hp_np == 2 ? s2_re : s1_re, *const z_im = t.hp_np == 2 ? s2_im : s1_im;
-      if (int rc = tilepass_chain<T>(t, m, t.hp_np, t.hp_l, t.hp_tw, 1u, window ? 4 : 3, batch, frames, window,
-                                     frame_stride, z_re, z_im, T(1), s1_re, s1_im, s2_re, s2_im, stream))
-        return rc;
-      const long long chunks = (m / 2 + 1 + 1023) / 1024;
+      // a window that is one of the plan's own tables (pdsp_plan_window_f32) is known by kind: the cosine sum is
+      // then evaluated in the first pass instead of being read back (4 more bytes per sample).
+      // first = tile_pass_kernel's IN: 3 rect, 4 window table, 5 / 6 fused two- / three-term window
+      int first = window ? 4 : 3;
+      pdsp::TileGeom fw{};
+      int kind = -1;
+      for (int k = 0; k < 4; ++k)
+        if (window && window == t.win[k]) kind = k;
+      if (kind == PDSP_WIN_RECT) first = 3;  // createWindow("rect") is all ones
+      if (t.hp_win && g_fused_window && kind > PDSP_WIN_RECT) {
+        fw.wa = t.hp_win, fw.wb = fw.wa + 2 * t.hp_win_a, fw.wstep = fw.wb + 2 * 512, fw.we = fw.wstep + 2 * 8;
+        if (kind == PDSP_WIN_HANN) first = 5, fw.k0 = 0.5f, fw.k1 = -0.5f;
+        else if (kind == PDSP_WIN_HAMMING) first = 5, fw.k0 = 0.54f, fw.k1 = -0.46f;
+        else if (kind == PDSP_WIN_BLACKMAN) first = 6, fw.k0 = 0.42f - 0.08f, fw.k1 = -0.5f, fw.k2 = 2 * 0.08f;
+      }
+      if (plan->log2n == 15 && t.tws4 && t.tw12 && g_split16k) {
+        // N = 32768: the 16384-point transform is one pass of fft_split4_kernel (14 bytes per sample in all)
+        const pdsp::StoreComplex<T> st{z_re, z_im, m, T(1)};
+#define PDSP_SPLIT4_PACKED(W)                                                                                         \
+  hipLaunchKernelGGL((pdsp::fft_split4_kernel<T, 12, pdsp::LoadPackedFrames<T, W>, pdsp::StoreComplex<T>>),           \
+                     dim3((unsigned)batch), dim3(256), 0, stream,                                                     \
+                     pdsp::LoadPackedFrames<T, W>{frames, window, frame_stride, fw.wb, fw.we + 2 * 8, fw.we, fw.k0,   \
+                                                  fw.k1, fw.k2},                                                      \
+                     st, t.tw12, t.tws4, batch)
+        switch (first) {
+          case 3: PDSP_SPLIT4_PACKED(0); break;
+          case 4: PDSP_SPLIT4_PACKED(1); break;
+          case 5: PDSP_SPLIT4_PACKED(2); break;
+          default: PDSP_SPLIT4_PACKED(3); break;
+        }
+#undef PDSP_SPLIT4_PACKED
+        PDSP_HIP_TRY(hipGetLastError());
+      } else {
+        if (int rc = tilepass_chain<T>(t, m, t.hp_np, t.hp_l, t.hp_tw, 1u, first, batch, frames, first == 4 ? window : nullptr,
+                                       frame_stride, z_re, z_im, T(1), s1_re, s1_im, s2_re, s2_im, stream,
+                                       first >= 5 ? &fw : nullptr))
+          return rc;
+      }
+      const long long chunks = m / 2048;  // 256 lanes of four pairs each
       if (batch * chunks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
       hipLaunchKernelGGL((pdsp::split_amp_rows_kernel<T>), dim3((unsigned)(batch * chunks)), dim3(256), 0, stream,
                          (const T *)z_re, (const T *)z_im, amp, ph, reinterpret_cast<const pdsp::cx<T> *>(t.twa),

@@ -333,6 +333,20 @@ __device__ __forceinline__ float mag(const cx<float> z) {
 __device__ __forceinline__ double mag(const cx<double> z) { return hypot(z.x, z.y); }
 
 // ---- load / store policies ------------------------------------------------
+// Eight consecutive values of a cosine-sum window (createWindow, fourier.ts:14-52) by angle addition, two per
+// packed instruction: c0 = (cos t, sin t) of the first sample, we[e] = (cos f e, sin f e) wave-uniform;
+// w[e] = k0 + k1 cos(t + f e), or k0 + c (k1 + k2 c) for the three-term window (cos 2t = 2 c^2 - 1 folded in).
+template <typename T, bool THREE>
+__device__ __forceinline__ void fused_window_pairs(const cx<T> c0, const cx<T> *__restrict__ we, const T k0, const T k1,
+                                                   const T k2, cx<T> (&w)[4]) {
+  static_for<4>([&](auto h) {
+    const cx<T> e0 = we[2 * h], e1 = we[2 * h + 1];
+    const cx<T> c = cx<T>{e0.x, e1.x} * c0.x - cx<T>{e0.y, e1.y} * c0.y;  // cos(t + f e), e = 2h, 2h + 1
+    if constexpr (THREE) w[h] = c * (c * k2 + k1) + k0;
+    else w[h] = c * k1 + k0;
+  });
+}
+
 // ld(row, off, lane) -> cx: fetch point off + lane of row `row` (row < batch).
 // st(row, off, lane, cx): write point off + lane.
 // `row` and `off` are wave-uniform whenever a transform spans whole waves, so
@@ -350,6 +364,7 @@ struct LoadComplex {  // forwardComplex / inverse (planes swapped by the caller)
   }
   static constexpr bool kPlanar = true;  // rows are contiguous planes: eligible for staged I/O
   static constexpr bool kHasIm = true;
+  static constexpr bool kPacked = false;
   __device__ __forceinline__ const T *plane_re() const { return re; }
   __device__ __forceinline__ const T *plane_im() const { return im; }
 };
@@ -363,8 +378,29 @@ struct LoadReal {  // Radix2Fft.forward: imaginary part is zero
   }
   static constexpr bool kPlanar = true;
   static constexpr bool kHasIm = false;
+  static constexpr bool kPacked = false;
   __device__ __forceinline__ const T *plane_re() const { return re; }
   __device__ __forceinline__ const T *plane_im() const { return nullptr; }
+};
+
+// Packed real frames for fft_split4_kernel: point m of the row is (x[2m], x[2m+1]) * (w[2m], w[2m+1]) of a
+// frame of 2N samples, `stride` samples apart (16-byte aligned) -- the first pass of the packed-real
+// spectrum path at N = 32768 (split_amp_rows_kernel undoes the packing).
+// WIN: 0 rect, 1 window table (2N values), 2 / 3 two- / three-term cosine-sum window evaluated in registers
+// (createWindow fused, fourier.ts:14-52): sample n = 8 (tid + 256 q) + e has, with f = 2 pi / (2N - 1) and
+// cs(t) = (cos t, sin t),  cs(f n) = wb[tid] * wq[q] * we[e]  (wb[j] = cs(8 f j), wq[q] = cs(2048 f q),
+// we[e] = cs(f e); f64-built), w = k0 + k1 c or k0 + c (k1 + k2 c), c = cos(f n).
+template <typename T, int WIN>
+struct LoadPackedFrames {
+  const T *__restrict__ x;
+  const T *__restrict__ win;
+  long long stride;
+  const float *wb, *wq, *we;
+  float k0, k1, k2;
+  static constexpr bool kPlanar = true;  // whole rows, vector loads
+  static constexpr bool kHasIm = true;
+  static constexpr bool kPacked = true;
+  static constexpr int kWin = WIN;
 };
 
 // Interleaved (re, im) rows -- the layout of I/Q streams and of complex64 tensors; one 8-byte
@@ -1476,7 +1512,6 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   const long long row = uniform_row<TP>((long long)blockIdx.x);
   if (row >= batch) return;
 
-  const V4 *const r4 = reinterpret_cast<const V4 *>(ld.plane_re() + (size_t)row * N);
   cx<T> a[E], b[E], c[E], d[E];
   RegTwiddles<T, LOG2S> twf;
   const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
@@ -1486,7 +1521,35 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
     w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
     load_order_fence();
   }
-  if constexpr (LD::kHasIm) {
+  if constexpr (LD::kPacked) {
+    // points 4m .. 4m+3 = samples 8m .. 8m+7 of the frame: two 16-byte loads (+ two of the window table)
+    const V4 *const f4 = reinterpret_cast<const V4 *>(ld.x + (size_t)row * (size_t)ld.stride);
+    cx<T> wcs{T(1), T(0)};
+    if constexpr (LD::kWin >= 2) wcs = reinterpret_cast<const cx<T> *>(ld.wb)[(unsigned)tid];
+    static_for<E>([&](auto q) {
+      // plain loads: the two halves of a lane's 32 bytes come from one cache line in two instructions, and
+      // the second finds it in L1 (non-temporal: -8 %, tools/ab_long_spectrum.py at N = 32768)
+      V4 r0 = f4[2 * (TP * q + (unsigned)tid)], r1 = f4[2 * (TP * q + (unsigned)tid) + 1];
+      if constexpr (LD::kWin == 1) {
+        const V4 *const w4 = reinterpret_cast<const V4 *>(ld.win);
+        r0 = r0 * w4[2 * (TP * q + (unsigned)tid)];
+        r1 = r1 * w4[2 * (TP * q + (unsigned)tid) + 1];
+      }
+      if constexpr (LD::kWin >= 2) {
+        static_assert(LD::kWin < 2 || (sizeof(T) == 4 && TP == 256), "fused windows: f32 rows of 16384 points");
+        const cx<T> c0 = cmul(wcs, reinterpret_cast<const cx<T> *>(ld.wq)[q]);  // wave-uniform: scalar loads
+        cx<T> w[4];
+        fused_window_pairs<T, LD::kWin == 3>(c0, reinterpret_cast<const cx<T> *>(ld.we), ld.k0, ld.k1, ld.k2, w);
+        r0 = r0 * V4{w[0].x, w[0].y, w[1].x, w[1].y};
+        r1 = r1 * V4{w[2].x, w[2].y, w[3].x, w[3].y};
+      }
+      a[q] = cx<T>{r0.x, r0.y};
+      b[q] = cx<T>{r0.z, r0.w};
+      c[q] = cx<T>{r1.x, r1.y};
+      d[q] = cx<T>{r1.z, r1.w};
+    });
+  } else if constexpr (LD::kHasIm) {
+    const V4 *const r4 = reinterpret_cast<const V4 *>(ld.plane_re() + (size_t)row * N);
     const V4 *const i4 = reinterpret_cast<const V4 *>(ld.plane_im() + (size_t)row * N);
     static_for<E>([&](auto q) {
       const V4 r = ld_stream(r4 + TP * q + (unsigned)tid);
@@ -1497,6 +1560,7 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
       d[q] = cx<T>{r.w, m.w};
     });
   } else {
+    const V4 *const r4 = reinterpret_cast<const V4 *>(ld.plane_re() + (size_t)row * N);
     static_for<E>([&](auto q) {
       const V4 r = ld_stream(r4 + TP * q + (unsigned)tid);
       a[q] = cx<T>{r.x, T(0)};
@@ -1886,6 +1950,14 @@ struct TileGeom {
                         // in real samples)
   unsigned tshift;      // 0, or 1 when twa / twb belong to a plan of 2N points (W_N^m = W_2N^(2m): the
                         // N/2-point transform of the packed-real spectrum path on its N-point plan's tables)
+  // IN = 5 / 6: createWindow fused into the packed first pass (cosine-sum windows, fourier.ts:14-52, evaluated by
+  // angle addition instead of being read back, 4 bytes per sample): with f = 2 pi / (frame length - 1) and
+  // cs(t) = (cos t, sin t), sample n = 8 u + 2 in_stride SPI ic + e has
+  //   cs(f n) = wa[u >> 9] * wb[u & 511] * wstep[ic] * we[e]     (wa[i] = cs(4096 f i), wb[j] = cs(8 f j),
+  //   wstep[ic] = cs(2 f in_stride SPI ic), we[e] = cs(f e); all built in f64 on the host)
+  // and w = k0 + k1 c (IN = 5) or k0 + c (k1 + k2 c) (IN = 6), c = cos(f n).
+  const float *wa, *wb, *wstep, *we;
+  float k0, k1, k2;
 };
 
 // IN (first pass only; in_im then carries the window table or nothing):
@@ -1895,13 +1967,16 @@ struct TileGeom {
 //   3  PACKED real rows: point m of the N-point transform is (x[2m], x[2m+1]) of a 2N-sample frame -- the
 //      packed-real form of spectrum() (split_amp_rows_kernel undoes the packing)
 //   4  packed real rows times the window table
+//   5  packed real rows times a two-term cosine-sum window evaluated in registers (TileGeom::wa ...)
+//   6  the same, three-term (blackman)
 template <typename T, int LOG2L, int TILE, bool COLS, int IN = 0>
 __global__ void __launch_bounds__(256)
 tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
                  const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
                  const cx<T> *__restrict__ twb, const TileGeom g, const T scale, const long long batch) {
   static_assert(IN == 0 || COLS, "real / packed / windowed input rides on the first (column) pass");
-  constexpr bool REAL_IN = IN == 1 || IN == 2, WINDOWED = IN == 2 || IN == 4, PACKED = IN >= 3;
+  constexpr bool REAL_IN = IN == 1 || IN == 2, WINDOWED = IN == 2 || IN == 4, PACKED = IN >= 3, FUSEDWIN = IN >= 5;
+  static_assert(!FUSEDWIN || sizeof(T) == 4, "fused windows: f32");
   using TR = FftTraits<LOG2L>;
   constexpr int L = TR::N, E = TR::E, TP = TR::TP, RPR = 256 / TP, ROUNDS = TILE / RPR;
   static_assert(LOG2L >= 6 && LOG2L <= 9 && TILE % RPR == 0 && TILE % 4 == 0 && ROUNDS >= 1, "tile of whole rounds");
@@ -1920,10 +1995,31 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
   const size_t base = (size_t)b * (size_t)g.n;
   const int seg = t / TS, j4 = (t % TS) * 4;
 
+  // COLS: the inter-pass twiddles W_N^(tmul (t0 + j4 + j) p), p = seg + SPI ic.  Tables first (the lesson of
+  // the single-pass kernels, PDSP_TABLES_FIRST): four two-level lookups per lane up here, their L2 latency
+  // under the tile's HBM loads, and one product per iteration below -- instead of four gathers per iteration
+  // between the transforms and the stores.  With q = tmul << tshift, J = t0 + j4:
+  //   w(ic)  = W^(q p J) = W^(q seg J) * (W^(q SPI J))^ic          first element of the lane's four
+  //   ws(ic) = W^(q p)   = W^(q seg)   * (W^(q SPI))^ic            step from element j to j + 1
+  cx<T> tw_w{T(1), T(0)}, tw_wv{T(1), T(0)}, tw_s{T(1), T(0)}, tw_su{T(1), T(0)};
+  if constexpr (COLS) {
+    const unsigned q = g.tmul << g.tshift, J = (unsigned)(t0 + j4);
+    const unsigned m0 = q * (unsigned)seg * J, mv = q * (unsigned)SPI * J;  // < N <= 2^27 (of the tables' plan)
+    const unsigned s0 = q * (unsigned)seg, su = q * (unsigned)SPI;
+    tw_w = cmul(twa[m0 >> 9], twb[m0 & 511]);
+    tw_wv = cmul(twa[mv >> 9], twb[mv & 511]);
+    tw_s = cmul(twa[s0 >> 9], twb[s0 & 511]);
+    tw_su = cmul(twa[su >> 9], twb[su & 511]);
+  }
   if constexpr (COLS) {
     // strided tile in: element (p, j) -> LDS row j, position p
     const size_t in_off = (size_t)blk * (size_t)g.in_blk + (size_t)(t0 + j4);  // index inside the frame
     const size_t ibase = (size_t)b * (size_t)g.in_batch + in_off;
+    cx<T> wcs{T(1), T(0)};  // FUSEDWIN: cs(f n) of the lane's first sample at ic = 0
+    if constexpr (FUSEDWIN) {
+      const unsigned u = (unsigned)((in_off + (size_t)seg * (size_t)g.in_stride) >> 2);  // sample index / 8
+      wcs = cmul(reinterpret_cast<const cx<T> *>(g.wa)[u >> 9], reinterpret_cast<const cx<T> *>(g.wb)[u & 511]);
+    }
     static_for<L / SPI>([&](auto ic) {
       const int p = seg + SPI * ic;
       if constexpr (PACKED) {
@@ -1934,6 +2030,14 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
         if constexpr (WINDOWED) {
           r0 = r0 * *reinterpret_cast<const V4 *>(in_im + fo);
           r1 = r1 * *(reinterpret_cast<const V4 *>(in_im + fo) + 1);
+        }
+        if constexpr (FUSEDWIN) {
+          const cx<T> *const wst = reinterpret_cast<const cx<T> *>(g.wstep), *const wee = reinterpret_cast<const cx<T> *>(g.we);
+          const cx<T> c0 = cmul(wcs, wst[ic]);  // wave-uniform step: scalar loads
+          cx<T> w[4];
+          fused_window_pairs<T, IN == 6>(c0, wee, g.k0, g.k1, g.k2, w);
+          r0 = r0 * V4{w[0].x, w[0].y, w[1].x, w[1].y};
+          r1 = r1 * V4{w[2].x, w[2].y, w[3].x, w[3].y};
         }
         cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
         d[0 * LROWX] = cx<T>{r0.x, r0.y};
@@ -1989,16 +2093,17 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
     const cx<T> *const d = lds + j4 * LROWX + lds_pad(p);
     cx<T> v[4] = {d[0 * LROWX], d[1 * LROWX], d[2 * LROWX], d[3 * LROWX]};
     if constexpr (COLS) {
-      // W_N^(tmul (t0 + j4 + j) p), j = 0..3: one two-level lookup for j = 0, then steps of W_N^(tmul p)
-      const unsigned mp = (g.tmul * (unsigned)p) << g.tshift;   // < N (of the tables' plan)
-      const unsigned m = mp * (unsigned)(t0 + j4);              // < N <= 2^27
-      cx<T> w = cmul(twa[m >> 9], twb[m & 511]);
-      const cx<T> ws = cmul(twa[mp >> 9], twb[mp & 511]);
+      // W_N^(tmul (t0 + j4 + j) p), j = 0..3: w(ic) for j = 0, then steps of ws(ic) (both advanced below)
+      cx<T> w = tw_w;
       v[0] = cmul(v[0], w);
       static_for<3>([&](auto jc) {
-        w = cmul(w, ws);
+        w = cmul(w, tw_s);
         v[jc + 1] = cmul(v[jc + 1], w);
       });
+      if constexpr (ic + 1 < L / SPI) {
+        tw_w = cmul(tw_w, tw_wv);
+        tw_s = cmul(tw_s, tw_su);
+      }
     } else {
       static_for<4>([&](auto jc) { v[jc] = v[jc] * scale; });
     }
@@ -2015,52 +2120,74 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
 // -- the same split spectrum_packed_kernel runs from LDS -- then magnitude + scaleAmplitude{One,Two}Sided
 // (+ phase), spectrum.ts:45-72, :121-131; two-sided rows get X[N - k] = conj(X[k]) as well.
 //   W_N^k = twa[k >> 9] * twb[k & 511] (the N-point plan's two-level table); bins = M + 1 or N.
+// One lane takes k = 4i .. 4i+3 (M/8 lanes per frame, M >= 2048): 16-byte loads of Z[4i ..] and of
+// Z[M-4i-4 .. M-4i-1] (the mirrors of 4i+1 .. 4i+3; Z[M-4i] is one more dword, Z[0] for lane 0), 16-byte
+// stores of bins 4i .. 4i+3 and M-4i-3 .. M-4i (rows of M + 1 bins: 4-byte aligned); lane 0 adds bin M/2.
 template <typename T>
 __global__ void __launch_bounds__(256)
 split_amp_rows_kernel(const T *__restrict__ zre, const T *__restrict__ zim, T *__restrict__ amp, T *__restrict__ ph,
                       const cx<T> *__restrict__ twa, const cx<T> *__restrict__ twb, const int M, const int bins,
                       const T s_edge, const T s_mid, const long long batch) {
-  const int per = M / 2 + 1;                       // pairs per frame
-  const int chunks = (per + 1023) / 1024;          // 1024 pairs per workgroup: four per lane, 256 apart
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  typedef T V4u __attribute__((ext_vector_type(4), aligned(4)));  // rows of M + 1 bins start anywhere
+  const int chunks = M / 8 / 256;
   const long long b = (long long)blockIdx.x / chunks;
-  const int c0 = (int)((long long)blockIdx.x % chunks) * 1024 + (int)threadIdx.x;
+  const int i = (int)((long long)blockIdx.x % chunks) * 256 + (int)threadIdx.x;
   if (b >= batch) return;
   const T *const re = zre + (size_t)b * (size_t)M, *const im = zim + (size_t)b * (size_t)M;
   T *const arow = amp + (size_t)b * (size_t)bins;
   T *const prow = ph ? ph + (size_t)b * (size_t)bins : nullptr;
   const bool two = bins > M + 1;
-  cx<T> z[4], zp[4];
-  static_for<4>([&](auto q) {
-    const int k = c0 + 256 * q, kc = k < per ? k : per - 1;  // unconditional clamped loads
-    const int km = (M - kc) & (M - 1);
-    z[q] = cx<T>{ld_stream(re + kc), ld_stream(im + kc)};
-    zp[q] = cx<T>{ld_stream(re + km), ld_stream(im + km)};
+  const int k0 = 4 * i;
+  const V4 fr = ld_stream(reinterpret_cast<const V4 *>(re + k0)), fi = ld_stream(reinterpret_cast<const V4 *>(im + k0));
+  const V4 mr = ld_stream(reinterpret_cast<const V4 *>(re + (M - k0 - 4)));
+  const V4 mi = ld_stream(reinterpret_cast<const V4 *>(im + (M - k0 - 4)));
+  const int km = (M - k0) & (M - 1);
+  const cx<T> m0{ld_stream(re + km), ld_stream(im + km)};
+  const cx<T> zh{re[M / 2], im[M / 2]};  // lane 0's extra bin (every lane loads it: no branch around a load)
+  const cx<T> wa = twa[k0 >> 9];
+  const V4 wb01 = *reinterpret_cast<const V4 *>(twb + (k0 & 511)), wb23 = *(reinterpret_cast<const V4 *>(twb + (k0 & 511)) + 1);
+  const cx<T> z[4] = {cx<T>{fr.x, fi.x}, cx<T>{fr.y, fi.y}, cx<T>{fr.z, fi.z}, cx<T>{fr.w, fi.w}};
+  const cx<T> zp[4] = {m0, cx<T>{mr.w, mi.w}, cx<T>{mr.z, mi.z}, cx<T>{mr.y, mi.y}};
+  const cx<T> wb[4] = {cx<T>{wb01.x, wb01.y}, cx<T>{wb01.z, wb01.w}, cx<T>{wb23.x, wb23.y}, cx<T>{wb23.z, wb23.w}};
+  cx<T> xa[4], xb[4];
+  T ma[4], mb[4];
+  static_for<4>([&](auto j) {
+    const cx<T> w = cmul(wa, wb[j]);
+    const cx<T> e = (z[j] + conj(zp[j])) * T(0.5), p = cmul(z[j] - conj(zp[j]), w) * T(0.5);
+    xa[j] = add_mul_neg_i(e, p), xb[j] = conj(add_mul_pos_i(e, p));  // X[k], X[M - k]
+    const T sc = (j == 0 && i == 0) ? s_edge : s_mid;                // k = 0 <-> bins 0 and M: DC and Nyquist
+    ma[j] = mag(xa[j]) * sc, mb[j] = mag(xb[j]) * sc;
   });
-  static_for<4>([&](auto q) {
-    const int k = c0 + 256 * q;
-    if (k < per) {
-      const cx<T> w = cmul(twa[k >> 9], twb[k & 511]);
-      const cx<T> e = (z[q] + conj(zp[q])) * T(0.5), p = cmul(z[q] - conj(zp[q]), w) * T(0.5);
-      const cx<T> xa = add_mul_neg_i(e, p), xb = conj(add_mul_pos_i(e, p));  // X[k], X[M - k]
-      const T sc = k == 0 ? s_edge : s_mid;  // k = 0 <-> bins 0 and M: DC and Nyquist
-      const T ma = mag(xa) * sc, mb = mag(xb) * sc;
-      const int k2 = M - k;
-      arow[k] = ma;
-      arow[k2] = mb;  // k = M/2: the same bin, the same value
-      if (prow) {
-        prow[k] = T(atan2(xa.y, xa.x));
-        prow[k2] = T(atan2(xb.y, xb.x));
-      }
-      if (two && k > 0) {  // X[N - k] = conj(X[k]), X[N - (M - k)] = X[M + k] = conj(X[M - k])
-        arow[2 * M - k] = ma;
-        arow[M + k] = mb;
+  *reinterpret_cast<V4u *>(arow + k0) = V4{ma[0], ma[1], ma[2], ma[3]};
+  *reinterpret_cast<V4u *>(arow + (M - k0 - 3)) = V4{mb[3], mb[2], mb[1], mb[0]};
+  if (prow) {
+    *reinterpret_cast<V4u *>(prow + k0) =
+        V4{T(atan2(xa[0].y, xa[0].x)), T(atan2(xa[1].y, xa[1].x)), T(atan2(xa[2].y, xa[2].x)), T(atan2(xa[3].y, xa[3].x))};
+    *reinterpret_cast<V4u *>(prow + (M - k0 - 3)) =
+        V4{T(atan2(xb[3].y, xb[3].x)), T(atan2(xb[2].y, xb[2].x)), T(atan2(xb[1].y, xb[1].x)), T(atan2(xb[0].y, xb[0].x))};
+  }
+  if (two) {  // X[N - k] = conj(X[k]) (k > 0), X[M + k] = conj(X[M - k])
+    static_for<4>([&](auto j) {
+      const int k = k0 + j;
+      if (k > 0) {
+        arow[2 * M - k] = ma[j];
+        arow[M + k] = mb[j];
         if (prow) {
-          prow[2 * M - k] = T(atan2(-xa.y, xa.x));
-          prow[M + k] = T(atan2(-xb.y, xb.x));
+          prow[2 * M - k] = T(atan2(-xa[j].y, xa[j].x));
+          prow[M + k] = T(atan2(-xb[j].y, xb[j].x));
         }
       }
+    });
+  }
+  if (i == 0) {  // X[M/2] = conj(Z[M/2]) pairs with itself
+    arow[M / 2] = mag(zh) * s_mid;
+    if (prow) prow[M / 2] = T(atan2(-zh.y, zh.x));
+    if (two) {
+      arow[M + M / 2] = mag(zh) * s_mid;
+      if (prow) prow[M + M / 2] = T(atan2(zh.y, zh.x));
     }
-  });
+  }
 }
 
 // ---- general four-step path: N = N1 * N2 with 32 <= N1 <= N2 = the largest single-pass size ---

@@ -187,8 +187,13 @@ def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_m
     x = (rng.standard_normal((3, n)) * 0.1 + np.sin(2 * np.pi * tone * t / n)).astype(np.float32)
     plan = BatchedFft(n, "cuda:0")
     dx = torch.from_numpy(x).cuda()
-    for window in ("rect", "hann"):
-        win = oracle_mod.create_window(window, n).astype(np.float32) if window != "rect" else None
+    # rect / hann / blackman by kind (the plan's own tables: createWindow fused into the first pass), hamming as
+    # the caller's own tensor (read as a table)
+    for window in ("rect", "hann", "blackman", "hamming-table") if log2n <= 20 else ("rect", "hann"):
+        kind = window.split("-")[0]
+        win = oracle_mod.create_window(kind, n).astype(np.float32) if kind != "rect" else None
+        if window.endswith("-table"):
+            window = torch.from_numpy(win).cuda()
         for sides in ("one", "two"):
             wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, two_sided=(sides == "two"),
                                                                want_phase=True, want_peak=True)
