@@ -253,11 +253,12 @@ def parity_vs_oracle(kind: str, inputs, outputs, n: int, window: str | None = No
             "ok": bool(err.max() <= 1e-5), "against": "oracle/pdsp_oracle.c (f64), rows drawn with seed 1337"}
 
 
-def read_clocks(dev=None):
-    """Current sclk / mclk of every amdgpu card sysfs shows (MHz), read once before and once after
-    timing -- context for the box-to-box spread of the same binary, not a measurement.
-    The host's other cards are listed too (they belong to other users); `"ours": true` marks the card
-    whose PCI address is the device this rank runs on."""
+def read_clocks(dev=None, ours_only=False):
+    """Current sclk / mclk of every amdgpu card sysfs shows (MHz), read before and after timing and once
+    UNDER LOAD (the ramp's launches still queued) -- context for the box-to-box spread of the same binary
+    (DESIGN 5), not a measurement.  The host's other cards are listed too (they belong to other users);
+    `"ours": true` marks the card whose PCI address is the device this rank runs on, and only that card
+    also gets fclk / socclk, board power (W) and the junction / memory temperatures (hwmon)."""
     import glob
     mine = None
     try:
@@ -268,15 +269,28 @@ def read_clocks(dev=None):
     out = []
     for d in sorted(glob.glob("/sys/class/drm/card*/device")):
         rec = {}
-        if mine and mine in os.path.realpath(d):
+        ours = bool(mine and mine in os.path.realpath(d))
+        if ours:
             rec["ours"] = True
-        for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        elif ours_only:
+            continue
+        files = [("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")]
+        if ours:
+            files += [("fclk_mhz", "pp_dpm_fclk"), ("socclk_mhz", "pp_dpm_socclk")]
+        for key, fn in files:
             try:
                 for line in open(os.path.join(d, fn)):
                     if line.rstrip().endswith("*"):
                         rec[key] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
             except Exception:
                 pass
+        if ours:
+            for key, pat, div in (("power_w", "power1_input", 1e6), ("power_cap_w", "power1_cap", 1e6),
+                                  ("temp_junction_c", "temp2_input", 1e3), ("temp_mem_c", "temp3_input", 1e3)):
+                try:
+                    rec[key] = round(int(open(glob.glob(os.path.join(d, "hwmon", "*", pat))[0]).read()) / div, 1)
+                except Exception:
+                    pass
         if rec:
             rec["card"] = os.path.basename(os.path.dirname(d))
             out.append(rec)
@@ -536,6 +550,15 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         for _ in range(10):
             step()
         torch.cuda.synchronize(dev)
+    clocks_load = None
+    if rank == 0:  # one reading with the card busy: the last ramp launches are still queued while sysfs is read
+        t_q = time.perf_counter()
+        for _ in range(40):
+            step()
+        busy = 40 * 0.6e-3 * launches_per_step  # >= 0.6 ms per launch on every workload here
+        time.sleep(max(0.0, min(0.25, 0.5 * busy) - (time.perf_counter() - t_q)))
+        clocks_load = read_clocks(dev, ours_only=True)
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -563,7 +586,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
 
     # context for the roofline fraction (outside the timed region): the rate at which this box, with
     # these very buffers, copies the input planes to the output planes (torch's device copy kernel)
-    copy_gbps = None
+    copy_gbps, copy_clocks = None, None
     if args.workload in ("fft4096", "fft16k") and rank == 0 and world == 1:
         for _ in range(3):
             ore.copy_(re)
@@ -576,6 +599,14 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         c1.record(stream)
         torch.cuda.synchronize(dev)
         copy_gbps = 10 * bytes_per_launch / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        # board power while the card only copies (0.5 s of copies queued), beside the FFT's reading above:
+        # says whether the transform runs against the power cap or the copy ceiling
+        for _ in range(350):
+            ore.copy_(re)
+            oim.copy_(im)
+        time.sleep(0.25)
+        copy_clocks = read_clocks(dev, ours_only=True)
+        torch.cuda.synchronize(dev)
         step()  # the output planes hold the transform again (parity rows are read below)
         torch.cuda.synchronize(dev)
 
@@ -654,7 +685,9 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                          "device_copy_same_buffers_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launch_ms_avg": launch_ms, "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
-            "clocks": {"before": clocks_before, "after": clocks_after, "source": "sysfs pp_dpm_sclk / pp_dpm_mclk"},
+            "clocks": {"before": clocks_before, "under_load": clocks_load, "after": clocks_after,
+                       "device_copy_under_load": copy_clocks,
+                       "source": "sysfs pp_dpm_* and hwmon of /sys/class/drm/card*/device"},
         }
         if world > 1:
             out["per_rank_kernel_ms"] = per_rank_ms
