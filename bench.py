@@ -29,6 +29,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -375,6 +376,8 @@ def parse_args(argv):
     ap.add_argument("--gather", action="store_true", help="(default at --gpus > 1; kept for older command lines)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the RCCL all-gather of the output slabs and of the peak records (timed on its own, after the timed region)")
+    ap.add_argument("--gather-timeout", type=float, default=150.0,
+                    help="N > 1: seconds the exchange leg may take before the line is printed without it")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no compute: launcher + rendezvous + shard + gather + max-over-ranks only (CPU tests)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="testing the launcher: this rank exits with status 3")
@@ -610,44 +613,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         step()  # the output planes hold the transform again (parity rows are read below)
         torch.cuda.synchronize(dev)
 
-    gather = None
-    if world > 1 and not args.no_gather and args.workload in ("fft4096", "real4096"):
-        # The one exchange step of the path, timed on its own.  (i) the full output slabs:
-        # at 2 GiB/rank the all-gather is xGMI-per-link bound and dwarfs the compute.  (ii) the reduced
-        # output a consumer of spectrum() needs -- one 16-byte SpectrumPeak per frame (fused findPeak
-        # over the rows' real plane): ~1 MiB/rank.
-        def timed_gather(tensors, rows_per_rank):
-            gather_rows(tensors[0][:8], 8 * world)  # communicator setup, untimed
-            barrier()
-            g0 = time.perf_counter()
-            outs = [gather_rows(t, rows_per_rank * world) for t in tensors]
-            torch.cuda.synchronize(dev)
-            sec = max_over_ranks(time.perf_counter() - g0, dev)
-            nbytes = sum(t.numel() * t.element_size() for t in tensors)
-            rows = int(outs[0].shape[0])
-            del outs
-            return {"ms": sec * 1e3, "bytes_per_rank": nbytes, "GBps_in_per_gpu": nbytes * (world - 1) / sec / 1e9,
-                    "rows_gathered": rows}
-        pk_i, pk_f, pk_a, pk_p, _, _ = plan.spectrum_peaks(re, "hann", "one", 48000.0)
-        recs = pk_i.new_empty((per_gpu, 4))
-        recs[:, 0] = pk_i
-        recs[:, 1:] = torch.stack([pk_f, pk_a, pk_p], dim=1).view(torch.int32)
-        torch.cuda.synchronize(dev)
-        try:  # the value above is already measured: a failed exchange is reported, not fatal
-            if args.dist_backend != "nccl":
-                # gloo rehearsal (1-GPU box): the collective runs on host copies, 4096 rows of the slabs per
-                # rank -- it checks the plumbing; it is not a bandwidth figure
-                gather = {"slabs": timed_gather([ore[:4096].cpu(), oim[:4096].cpu()], 4096),
-                          "peaks_16B_per_frame": timed_gather([recs.cpu()], per_gpu),
-                          "note": "gloo rehearsal on host copies (slabs: 4096 rows per rank)"}
-            else:
-                # the small exchange first: it is the one a consumer of spectrum() needs
-                gather = {"peaks_16B_per_frame": timed_gather([recs], per_gpu)}
-                gather["slabs"] = timed_gather([ore, oim], per_gpu)
-        except Exception as exc:  # noqa: BLE001  (RuntimeError from RCCL / allocator)
-            gather = dict(gather or {}, error=f"{type(exc).__name__}: {exc}"[:300])
-        gather["backend"] = args.dist_backend
-
+    out = None
     if rank == 0:
         samples_per_step = per_gpu * n * world
         value = samples_per_step * args.steps / elapsed / 1e9
@@ -696,8 +662,6 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                                     "note": "sum of all ranks' samples / max-over-ranks wall time; no collective inside"}
             if args.share_gpu:
                 out["rehearsal"] = "all ranks share cuda:0 (1-GPU box): plumbing check, not a scaling point"
-        if gather:
-            out["gather"] = gather
         if not args.no_cpu_baseline:
             # CPU legs, rank 0 only, after the timed region: (i) parity of 256 rows of the timed output
             # against the oracle, (ii) the oracle timed as the CPU baseline (N = 1 only)
@@ -721,15 +685,87 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
             hre = re[sel.to(dev)].cpu().numpy().astype(np.float64)
             him = im[sel.to(dev)].cpu().numpy().astype(np.float64) if im is not None else None
             out["cpu_baseline"] = cpu_baseline(hre, him, n, args.cpu_seconds)
-        bad = [k for k in ("parity",) if k in out and not out[k]["ok"]]
-        if "also" in out and "parity" in out["also"]["spectrum16k"] and not out["also"]["spectrum16k"]["parity"]["ok"]:
-            bad.append("also.spectrum16k.parity")
+    # The one exchange step of the path, timed on its own AFTER the line is assembled: the value is
+    # already measured, so neither a failed nor a hung exchange may take it away.  A watchdog thread prints rank 0's
+    # line with `gather.error` and ends every rank with status 0 if the exchange has not returned in time.
+    gather = None
+    if world > 1 and not args.no_gather and args.workload in ("fft4096", "real4096"):
+        gather = {"backend": args.dist_backend}
+        exchange_done, lock = threading.Event(), threading.Lock()
+
+        def watchdog():
+            if exchange_done.wait(args.gather_timeout):
+                return
+            with lock:  # the main thread is inside a collective, not inside an update of `gather`
+                gather["error"] = f"exchange still running after {args.gather_timeout:g} s: abandoned, the measured value stands"
+                if rank == 0:
+                    out["gather"] = gather
+                    print(json.dumps(out), flush=True)
+            if rank != 0:
+                time.sleep(2.0)  # rank 0 prints first
+            os._exit(4 if (rank == 0 and parity_failures(out)) else 0)
+        threading.Thread(target=watchdog, daemon=True).start()
+
+        # (i) the full output slabs: at 2 GiB/rank the all-gather is xGMI-per-link bound and dwarfs the compute.
+        # (ii) the reduced output a consumer of spectrum() needs -- one 16-byte SpectrumPeak per frame (fused
+        # findPeak over the rows' real plane): ~1 MiB/rank.
+        def timed_gather(tensors, rows_per_rank):
+            gather_rows(tensors[0][:8], 8 * world)  # communicator setup, untimed
+            barrier()
+            g0 = time.perf_counter()
+            outs = [gather_rows(t, rows_per_rank * world) for t in tensors]
+            torch.cuda.synchronize(dev)
+            sec = max_over_ranks(time.perf_counter() - g0, dev)
+            nbytes = sum(t.numel() * t.element_size() for t in tensors)
+            rows = int(outs[0].shape[0])
+            del outs
+            return {"ms": sec * 1e3, "bytes_per_rank": nbytes, "GBps_in_per_gpu": nbytes * (world - 1) / sec / 1e9,
+                    "rows_gathered": rows}
+        try:  # a failed exchange is reported, not fatal
+            pk_i, pk_f, pk_a, pk_p, _, _ = plan.spectrum_peaks(re, "hann", "one", 48000.0)
+            recs = pk_i.new_empty((per_gpu, 4))
+            recs[:, 0] = pk_i
+            recs[:, 1:] = torch.stack([pk_f, pk_a, pk_p], dim=1).view(torch.int32)
+            torch.cuda.synchronize(dev)
+            if args.dist_backend != "nccl":
+                # gloo rehearsal (1-GPU box): the collective runs on host copies, 4096 rows of the slabs per
+                # rank -- it checks the plumbing; it is not a bandwidth figure
+                legs = (("slabs", lambda: timed_gather([ore[:4096].cpu(), oim[:4096].cpu()], 4096)),
+                        ("peaks_16B_per_frame", lambda: timed_gather([recs.cpu()], per_gpu)))
+                with lock:
+                    gather["note"] = "gloo rehearsal on host copies (slabs: 4096 rows per rank)"
+            else:
+                # the small exchange first: it is the one a consumer of spectrum() needs
+                legs = (("peaks_16B_per_frame", lambda: timed_gather([recs], per_gpu)),
+                        ("slabs", lambda: timed_gather([ore, oim], per_gpu)))
+            for name, leg in legs:
+                res = leg()
+                with lock:
+                    gather[name] = res
+        except Exception as exc:  # noqa: BLE001  (RuntimeError from RCCL / allocator)
+            with lock:
+                gather["error"] = f"{type(exc).__name__}: {exc}"[:300]
+        finally:
+            exchange_done.set()
+
+    if rank == 0:
+        if gather:
+            out["gather"] = gather
+        bad = parity_failures(out)
         print(json.dumps(out), flush=True)
         if bad:  # a fast kernel whose results differ from the reference's is not done: say so loudly
             print(f"bench.py: PARITY FAILED against the oracle ({', '.join(bad)}): the line above is not a valid measurement",
                   file=sys.stderr)
             return 4
     return 0
+
+
+def parity_failures(out) -> list:
+    """Names of the in-run oracle checks of a bench line that failed (empty = the line is a valid measurement)."""
+    bad = [k for k in ("parity",) if k in out and not out[k]["ok"]]
+    if "also" in out and "parity" in out["also"]["spectrum16k"] and not out["also"]["spectrum16k"]["parity"]["ok"]:
+        bad.append("also.spectrum16k.parity")
+    return bad
 
 
 def also_spectrum16k(args, dev, rank: int):

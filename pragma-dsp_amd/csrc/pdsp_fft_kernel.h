@@ -1745,7 +1745,6 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   const cx<T> *const z2 = reinterpret_cast<const cx<T> *>(frames + (size_t)row * (size_t)stride);
   cx<T> a[E], b[E];
   if constexpr (PDSP_DIF_BUFFER && sizeof(T) == 4) {
-    typedef unsigned U2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<cx<T> *>(z2), 0, 2 * M * (int)sizeof(T), 0x00020000);
     const int vo = tid * 8;
