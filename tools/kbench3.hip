@@ -26,14 +26,16 @@ typedef float V4 __attribute__((ext_vector_type(4)));
 template <int W, bool RS, bool WS>
 __global__ void __launch_bounds__(256)
 tile_move(const float *__restrict__ in_re, const float *__restrict__ in_im, float *__restrict__ out_re,
-          float *__restrict__ out_im, const int pitch, const int tiles_per_row, const int lds_bytes) {
+          float *__restrict__ out_im, const int pitch, const int tiles_per_row, const int lds_bytes,
+          const int spread = 1) {
   extern __shared__ float dummy[];
   constexpr int TS = W / 4, SPI = 256 / TS, R = 8192 / W, NIT = R / SPI;
   const int t = (int)threadIdx.x;
   const size_t blk = blockIdx.x;
   const size_t band = blk / tiles_per_row, tile = blk % tiles_per_row;  // a band = R rows of the matrix
   const size_t sbase = band * (size_t)R * (size_t)pitch + tile * W;       // strided tile origin
-  const size_t cbase = blk * 8192;                                        // contiguous chunk origin
+  // contiguous chunk origin; spread S > 1: workgroups b, b+1, ... take chunks gridDim/S apart (S concurrent fronts)
+  const size_t cbase = (spread > 1 ? (blk % spread) * (gridDim.x / spread) + blk / spread : blk) * 8192;
   const int seg = t / TS, j4 = (t % TS) * 4;
   V4 r[NIT], m[NIT];
 #pragma unroll
@@ -71,6 +73,25 @@ double run(const float *a, const float *b, float *c, float *d, size_t floats, in
   return 16.0 * (double)floats / (ms / rounds * 1e-3) / 1e12;  // TB/s: 8 B read + 8 B written per float pair
 }
 
+// contiguous 32 KB chunks per plane (the shape of a row kernel's workgroup), consecutive workgroups `spread` fronts apart
+double run_spread(const float *a, const float *b, float *c, float *d, size_t floats, int spread, int lds, int rounds) {
+  const int blocks = (int)(floats / 8192);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_move<256, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL((tile_move<256, false, false>), dim3(blocks), dim3(256), lds, 0, a, b, c, d, 256, 1, lds, spread);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < rounds; ++i)
+    hipLaunchKernelGGL((tile_move<256, false, false>), dim3(blocks), dim3(256), lds, 0, a, b, c, d, 256, 1, lds, spread);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return 16.0 * (double)floats / (ms / rounds * 1e-3) / 1e12;
+}
+
 int main(int argc, char **argv) {
   const size_t floats = (size_t)1 << 27;  // per plane: 512 MiB, 2 GiB of traffic per launch
   const int rounds = argc > 1 ? atoi(argv[1]) : 10;
@@ -81,6 +102,11 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&d, floats * 4));
   CK(hipMemset(a, 0, floats * 4));
   CK(hipMemset(b, 0, floats * 4));
+  printf("contiguous 32 KB chunks, consecutive workgroups on S fronts gridDim/S chunks apart (TB/s), 4 workgroups per CU\n");
+  for (int rep = 0; rep < 2; ++rep)
+    for (int spread : {1, 2, 8, 16, 64, 256, 1024, 4096, 16384})
+      printf("  S = %5d  %6.2f\n", spread, run_spread(a, b, c, d, floats, spread, 36 * 1024, rounds));
+  if (argc > 2) return 0;
   printf("TB/s of traffic, 2^27 complex points per launch; rows of a tile are `pitch` floats apart\n");
   printf("%6s %6s %9s | %8s %8s %8s %8s\n", "pitch", "wg/CU", "segment", "rs+ws", "rs+wc", "rc+ws", "rc+wc");
   for (int pitch : {256, 4096, 65536}) {
