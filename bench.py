@@ -657,8 +657,13 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         }
         if world > 1:
             out["per_rank_kernel_ms"] = per_rank_ms
+            # each rank's own kernel against ITS card's HBM peak, and the whole job against world x peak
+            out["per_rank_roofline_frac"] = [bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS for ms in per_rank_ms]
             out["compute_phase"] = {"GSample_per_s": value, "samples_per_step": samples_per_step,
                                     "max_rank_ms_per_step": elapsed / args.steps * 1e3,
+                                    "algorithmic_GBps_all_ranks": bytes_per_launch * launches_per_step * world * args.steps / elapsed / 1e9,
+                                    "frac_of_world_x_hbm_peak": bytes_per_launch * launches_per_step * world * args.steps / elapsed / 1e9
+                                    / (HBM_PEAK_GBPS * world),
                                     "note": "sum of all ranks' samples / max-over-ranks wall time; no collective inside"}
             if args.share_gpu:
                 out["rehearsal"] = "all ranks share cuda:0 (1-GPU box): plumbing check, not a scaling point"
