@@ -558,8 +558,15 @@ int tilepass_chain(const Tables<T> &t, long long n, int np, const int *l, typena
   const long long a = 1LL << l[0], b = 1LL << l[1], c = 1LL << l[2];
   pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(l[0])), 0, 0, b * c, b * c, 1u, in_batch, tshift};
   with_window(g1);
-  if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
   pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(l[1])), b * c, c, c, a * c, (unsigned)a, n, tshift};
+  if (!(g_twopass & 2)) {
+    // the scratch planes between the first two passes tile-major (TileGeom::perm_*): the second pass reads its
+    // [B][TILE] tiles as contiguous chunks; pdsp_set_twopass bit 1 keeps them in natural order (A/B tests)
+    const int lt = l[1] == 6 ? 6 : (l[1] == 9 ? 4 : 5);  // log2 tile_width(l[1])
+    g1.perm_lc = l[2], g1.perm_lt = lt, g1.perm_b = (int)b;
+    g2.in_tile = b << lt, g2.in_stride = 1LL << lt;
+  }
+  if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
   if (int rc = tile_pass<T, true>(l[1], 0, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, tw[1], t, g2, T(1), batch, s))
     return rc;
   pdsp::TileGeom g3{n, 1, (int)(a * b / tile_width(l[2])), 0, 0, 0, a * b, 1u, n, tshift};
@@ -595,7 +602,7 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   if constexpr (sizeof(T) == 4) {
     // tile passes with balanced factors (two for 2^15..2^17, three for 2^19..2^27) where the tables exist and
     // every plane is 16-byte aligned; pdsp_set_twopass(0) keeps round 1's four-step forms (A/B tests)
-    if (t.tp_np && g_twopass &&
+    if (t.tp_np && (g_twopass & 1) &&
         (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {
       const size_t plane = (size_t)batch * (size_t)plan->n;
       const bool aliased = re_out == re_in || re_out == im_in || im_out == re_in || im_out == im_in;
@@ -1134,7 +1141,7 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     // N = 2^15); split_amp_rows_kernel undoes the packing on the way to the amplitude (+ phase) rows.  HBM
     // bytes per sample: 4+4, 4+4 (, 4+4), 4+2 = 22 (30) where the four-step forms on (x*w, 0) move 38 (70).  The four-step forms stay for partial /
     // unaligned frames and f64.
-    if (t.log2n1 > 0 && t.hp_np && g_twopass && used == n && (frame_stride & 3) == 0 &&
+    if (t.log2n1 > 0 && t.hp_np && (g_twopass & 1) && used == n && (frame_stride & 3) == 0 &&
         (((uintptr_t)frames | (uintptr_t)window) & 15) == 0) {
       T *amp = amp_out, *ph = phase_out;
       const long long m = n / 2;
@@ -1503,7 +1510,7 @@ int pdsp_set_split16k(int enabled) {
 
 int pdsp_set_twopass(int enabled) {
   const int prev = g_twopass;
-  g_twopass = enabled ? 1 : 0;
+  g_twopass = enabled & 3;  // bit 0: tile passes; bit 1: natural-order scratch between the first two of three
   return prev;
 }
 

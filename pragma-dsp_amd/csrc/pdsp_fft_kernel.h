@@ -1957,6 +1957,14 @@ struct TileGeom {
   // and w = k0 + k1 c (IN = 5) or k0 + c (k1 + k2 c) (IN = 6), c = cos(f n).
   const float *wa, *wb, *wstep, *we;
   float k0, k1, k2;
+  // Scratch planes between the first two of three passes, TILE-MAJOR (0 = natural order everywhere): a strided
+  // tile costs its READER (the column passes run at 4.9-5.7 TB/s, the row passes -- contiguous reads, strided
+  // writes -- at 6.1-6.3), so the first pass writes column n' = n2 C + n3 of every row block to
+  //   ((n3 >> perm_lt) * perm_b + n2) << perm_lt | (n3 & (2^perm_lt - 1))       (perm_lc = log2 C, perm_b = B)
+  // i.e. the [B][2^perm_lt] tile the second pass needs becomes one contiguous chunk (in_tile = B << perm_lt apart,
+  // in_stride = 2^perm_lt), and the first pass still writes segments of the same width at the same stride.
+  int perm_lc, perm_lt, perm_b;  // output side; perm_lt == 0: no permutation
+  long long in_tile;            // input side: distance between the origins of consecutive tiles (0: TILE)
 };
 
 // IN (first pass only; in_im then carries the window table or nothing):
@@ -2012,7 +2020,8 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
   }
   if constexpr (COLS) {
     // strided tile in: element (p, j) -> LDS row j, position p
-    const size_t in_off = (size_t)blk * (size_t)g.in_blk + (size_t)(t0 + j4);  // index inside the frame
+    const size_t in_off = (size_t)blk * (size_t)g.in_blk +
+                          (g.in_tile ? (size_t)(t0 / TILE) * (size_t)g.in_tile + (size_t)j4 : (size_t)(t0 + j4));  // index inside the frame
     const size_t ibase = (size_t)b * (size_t)g.in_batch + in_off;
     cx<T> wcs{T(1), T(0)};  // FUSEDWIN: cs(f n) of the lane's first sample at ic = 0
     if constexpr (FUSEDWIN) {
@@ -2086,7 +2095,14 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
   __syncthreads();
 
   // strided tile out: element (p, j) -> out[... + p*out_stride + j]
-  const size_t obase = COLS ? base + (size_t)blk * (size_t)g.out_blk + (size_t)(t0 + j4) : base + (size_t)(t0 + j4);
+  size_t ocol = (size_t)(t0 + j4);
+  if constexpr (COLS) {
+    if (g.perm_lt) {  // tile-major scratch (TileGeom): the lane's four columns stay adjacent (2^perm_lt >= 16)
+      const unsigned np = (unsigned)(t0 + j4), n2 = np >> g.perm_lc, n3 = np & ((1u << g.perm_lc) - 1u);
+      ocol = ((size_t)((n3 >> g.perm_lt) * (unsigned)g.perm_b + n2) << g.perm_lt) | (size_t)(n3 & ((1u << g.perm_lt) - 1u));
+    }
+  }
+  const size_t obase = COLS ? base + (size_t)blk * (size_t)g.out_blk + ocol : base + ocol;
   static_for<L / SPI>([&](auto ic) {
     const int p = seg + SPI * ic;
     const cx<T> *const d = lds + j4 * LROWX + lds_pad(p);

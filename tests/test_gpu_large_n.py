@@ -131,7 +131,8 @@ def test_general_four_step_n_2_24(oracle_mod):
 def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
     """f32 transforms beyond the single-pass limit on tile_pass_kernel -- balanced factors, two passes over
     HBM for 2^15 <= N <= 2^17 and three for 2^19 <= N <= 2^27 (2^18 stays on the four-step form either
-    way) -- against round 1's four-step forms (pdsp_set_twopass(0): three / five passes) and the oracle:
+    way), the scratch planes between the first two of three passes tile-major (default) and in natural order
+    (pdsp_set_twopass(3): bit-identical results) -- against round 1's four-step forms (pdsp_set_twopass(0): three / five passes) and the oracle:
     complex, real input, inverse, an in-place call (output planes = input planes) and an odd batch."""
     import torch
     from pragma_dsp_amd.batch import BatchedFft
@@ -148,7 +149,7 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
     want = wre + 1j * wim
     rre_w, rim_w = oracle_mod.Plan(n).forward(re)
     res = {}
-    for mode in (1, 0):
+    for mode in (1, 3, 0):   # 3: the scratch planes between the first two of three passes in natural order
         prev = pdsp.lib.pdsp_set_twopass(mode)
         try:
             dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
@@ -169,6 +170,7 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
             pdsp.lib.pdsp_set_twopass(prev)
         res[mode] = got
     assert rel_err(res[1], res[0]) <= 2e-6
+    assert np.array_equal(res[1], res[3])                 # the same arithmetic, another scratch layout
 
 
 @pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20, 21, 22, 24])
@@ -198,7 +200,7 @@ def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_m
             wamp, wph, wpk = oracle_mod.Plan(n).spectrum_batch(x, window=win, two_sided=(sides == "two"),
                                                                want_phase=True, want_peak=True)
             res = {}
-            for mode in (1, 0):
+            for mode in (1, 3, 0):
                 prev = pdsp.lib.pdsp_set_twopass(mode)
                 try:
                     amp, ph, pk = plan.spectrum(dx, window, sides, want_phase=True, want_peak=True)
@@ -212,7 +214,7 @@ def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_m
                 d = np.abs((ph.cpu().numpy() - wph + np.pi) % (2 * np.pi) - np.pi)
                 assert d[mask].max() <= 2e-3
                 res[mode] = a
-            assert rel_err(res[1], res[0]) <= 2e-6
+            assert rel_err(res[1], res[0]) <= 2e-6 and np.array_equal(res[1], res[3])
     idx, freq, a, p, _, _ = plan.spectrum_peaks(dx, "hann", "one", 48000.0)
     assert [int(v) for v in idx.cpu()] == [tone] * 3
     short = torch.from_numpy(x[:, : n - 1000].copy()).cuda()          # zero-padded frames: four-step form

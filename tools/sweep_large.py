@@ -33,11 +33,12 @@ for log2n in (15, 16, 17, 18, 19, 20, 22, 24, 26):
     t = timed(lambda: plan.forward(re, im, out=(ore, oim)))
     c = 16.0 * batch * n / t / 1e9
     line = f"{n:10d} {2 if log2n <= 17 else 3:7d} {c:10.0f} {c/8000:6.3f} {batch*n/t/1e9:10.1f}"
-    if True:  # A/B: round 1's four-step forms (three passes up to 2^18, five above)
+    if True:  # A/B: natural-order scratch between passes 1 and 2 (3); round 1's four-step forms (0)
         from pragma_dsp_amd import _capi
-        prev = _capi.lib.pdsp_set_twopass(0)
-        t3 = timed(lambda: plan.forward(re, im, out=(ore, oim)))
-        _capi.lib.pdsp_set_twopass(prev)
-        line += f"   (round-1 four-step: {16.0 * batch * n / t3 / 1e9:6.0f} GB/s)"
+        for mode, label in ((3, "natural-order scratch"), (0, "round-1 four-step")):
+            prev = _capi.lib.pdsp_set_twopass(mode)
+            t3 = timed(lambda: plan.forward(re, im, out=(ore, oim)))
+            _capi.lib.pdsp_set_twopass(prev)
+            line += f"   ({label}: {16.0 * batch * n / t3 / 1e9:6.0f} GB/s)"
     print(line, flush=True)
     del re, im, ore, oim, plan
