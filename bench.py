@@ -14,9 +14,11 @@ and exits non-zero if any child failed.  The batch is split by rank with no data
 collective (weak scaling: 65,536 transforms per GPU, configs[4] at N=8 -- the batch idiom
 of bench/reallife/signals.ts:264-270 generalised), and the timed region is bracketed by
 a barrier + synchronize with the MAX over ranks taken.  Rank 0 prints ONE JSON line.
-At N > 1 the one exchange step of the path follows the timed region and is timed
-on its own (`--no-gather` skips it): the RCCL all-gather of the output slabs and of the
-16-byte-per-frame SpectrumPeak records.
+The control plane (barriers, the MAX, per-rank read-outs: host scalars) runs over gloo on loopback;
+RCCL carries the path's one exchange step, which at N > 1 follows the timed region and is
+timed on its own (`--no-gather` skips it): the all-gather over xGMI of the output slabs and of the
+16-byte-per-frame SpectrumPeak records, under a watchdog (`--gather-timeout`) -- a failed or hung
+exchange is reported in the line, the measured value stands.
 
 Other workloads (parity-checked elsewhere; here for DESIGN.md's numbers):
   --workload spectrum16k   configs[3]: fused Hann+FFT+one-sided amplitude, N=16384,
@@ -371,7 +373,9 @@ def parse_args(argv):
     ap.add_argument("--no-also", action="store_true", help="skip the short configs[3] leg attached to the default line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ramp-seconds", type=float, default=0.6, help="untimed clock-ramp before the warm-up steps")
-    ap.add_argument("--dist-backend", default=None, help="nccl (= RCCL, default) or gloo (default with --share-gpu / --dry-run)")
+    ap.add_argument("--dist-backend", default=None,
+                    help="backend of the exchange leg: nccl (= RCCL, default) or gloo (default with --share-gpu / --dry-run); "
+                         "the control plane is always gloo")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="(default at --gpus > 1; kept for older command lines)")
     ap.add_argument("--no-gather", action="store_true",
@@ -429,10 +433,12 @@ def main(argv=None) -> int:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(args.dist_backend)
+        # Control plane (barriers, max-over-ranks, per-rank read-outs: a few host scalars) over gloo on loopback --
+        # one node, nothing of it inside a kernel's time -- so that the timed measurement does not depend on the
+        # health of the collective library; RCCL (backend "nccl") carries the path's one exchange step, the final
+        # gather (north_star: "RCCL over xGMI only for the final gather"), as its own group, created in that leg.
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo")
     try:
         if args.dry_run:
             return dry_run(args, world, rank)
@@ -539,10 +545,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            if args.dist_backend == "nccl":
-                dist.barrier(device_ids=[local])
-            else:
-                dist.barrier()
+            dist.barrier()
         torch.cuda.synchronize(dev)
 
     clocks_before = read_clocks(dev) if rank == 0 else None
@@ -577,12 +580,12 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     clocks_after = read_clocks(dev) if rank == 0 else None
 
-    elapsed = max_over_ranks(elapsed_local, dev)
+    elapsed = max_over_ranks(elapsed_local)
     launch_ms = float(np.mean(step_ms)) / launches_per_step
     per_rank_ms = [launch_ms]
     if world > 1:  # every rank's own kernel time (HIP events on its stream), for the scaling read-out
         import torch.distributed as dist
-        t = torch.tensor([launch_ms], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        t = torch.tensor([launch_ms], dtype=torch.float64)
         allms = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allms, t)
         per_rank_ms = [float(x.item()) for x in allms]
@@ -714,13 +717,15 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         # (i) the full output slabs: at 2 GiB/rank the all-gather is xGMI-per-link bound and dwarfs the compute.
         # (ii) the reduced output a consumer of spectrum() needs -- one 16-byte SpectrumPeak per frame (fused
         # findPeak over the rows' real plane): ~1 MiB/rank.
+        xgrp = [None]  # the exchange group: RCCL (created below, inside the guarded leg), or the gloo default group
+
         def timed_gather(tensors, rows_per_rank):
-            gather_rows(tensors[0][:8], 8 * world)  # communicator setup, untimed
+            gather_rows(tensors[0][:8], 8 * world, xgrp[0])  # communicator warm-up, untimed
             barrier()
             g0 = time.perf_counter()
-            outs = [gather_rows(t, rows_per_rank * world) for t in tensors]
+            outs = [gather_rows(t, rows_per_rank * world, xgrp[0]) for t in tensors]
             torch.cuda.synchronize(dev)
-            sec = max_over_ranks(time.perf_counter() - g0, dev)
+            sec = max_over_ranks(time.perf_counter() - g0)
             nbytes = sum(t.numel() * t.element_size() for t in tensors)
             rows = int(outs[0].shape[0])
             del outs
@@ -740,6 +745,19 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                 with lock:
                     gather["note"] = "gloo rehearsal on host copies (slabs: 4096 rows per rank)"
             else:
+                # RCCL comes up here, as a group of its own (one communicator per rank, bound to its card); the
+                # ranks then agree over the control plane that it did, so that a failed bring-up is skipped by
+                # all of them together instead of leaving some inside a collective
+                import torch.distributed as dist
+                up, why = 1.0, ""
+                try:
+                    xgrp[0] = dist.new_group(backend="nccl", device_id=dev)
+                    gather_rows(recs[:8], 8 * world, xgrp[0])
+                    torch.cuda.synchronize(dev)
+                except Exception as exc:  # noqa: BLE001
+                    up, why = 0.0, f"{type(exc).__name__}: {exc}"
+                if max_over_ranks(1.0 - up) > 0.0:
+                    raise RuntimeError("RCCL group did not come up on every rank" + (f" (this rank: {why})" if why else ""))
                 # the small exchange first: it is the one a consumer of spectrum() needs
                 legs = (("peaks_16B_per_frame", lambda: timed_gather([recs], per_gpu)),
                         ("slabs", lambda: timed_gather([ore, oim], per_gpu)))
