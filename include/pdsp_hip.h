@@ -114,9 +114,10 @@ PDSP_API int pdsp_set_fused_window(int enabled);
 /* 1 (default): f32 transforms of 2^15 <= N <= 2^27 on 16-byte aligned planes run as tile passes over
  * balanced factors of 64 ... 512 points (tile_pass_kernel): TWO passes over HBM up to 2^17, THREE above;
  * 0: round 1's four-step forms (N1 <= 16 columns, 16384-point rows, transposing copy: three passes up to
- * 2^18, five above); 3: tile passes with the scratch planes between the first two of three passes in natural
- * order instead of tile-major (the second pass then reads strided).  Same results (mode 3: bit for bit);
- * A/B switch, returns the previous value. */
+ * 2^18, five above); 3: tile passes in their first form -- the scratch planes between the first two of three
+ * passes in natural order instead of tile-major (bit-identical results), a 512-point last factor on 16-row
+ * tiles instead of tile_rows512_kernel's 32 (same results within rounding).  A/B switch, returns the previous
+ * value. */
 PDSP_API int pdsp_set_twopass(int enabled);
 
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).

@@ -114,6 +114,7 @@ struct Tables {
   int tp_np = 0;
   int tp_l[3] = {0, 0, 0};
   T2 *tp_tw[3] = {nullptr, nullptr, nullptr};
+  T2 *tw8 = nullptr;  // radix table of the 256-point transform (tile_rows512_kernel's halves of a 512-point factor)
   // the same for the N/2-point transform of the packed-real spectrum path (2^15 <= N <= 2^27): it runs on
   // this plan's twa / twb with doubled exponents (TileGeom::tshift)
   int hp_np = 0;
@@ -132,6 +133,8 @@ struct Tables {
     if (tws2) (void)hipFree(tws2);
     tws2 = nullptr;
 
+    if (tw8) (void)hipFree(tw8);
+    tw8 = nullptr;
     for (T2 *&q : tp_tw) {
       if (q) (void)hipFree(q);
       q = nullptr;
@@ -498,6 +501,18 @@ int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *
   if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
   const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
   const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
+  if constexpr (!COLS && sizeof(T) == 4) {
+    // a 512-point factor as the last pass: 32-row tiles through tile_rows512_kernel (128-byte output segments)
+    // instead of 16-row ones; pdsp_set_twopass bit 1 keeps the plain tiles (A/B tests)
+    if (l == 9 && t.tw8 && !(g_twopass & 2) && g.tiles % 2 == 0) {
+      g.tiles /= 2;
+      const long long wide = batch * g.tiles;
+      hipLaunchKernelGGL((pdsp::tile_rows512_kernel<T>), dim3((unsigned)wide), dim3(256), 0, s, in_re, in_im, out_re, out_im,
+                         t.tw8, twa, twb, g, scale, batch);
+      PDSP_HIP_TRY(hipGetLastError());
+      return PDSP_OK;
+    }
+  }
 #define PDSP_TILE_IN(L, TILE, IN)                                                                                  \
   hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, ((COLS && (IN < 5 || sizeof(T) == 4)) ? IN : 0)>),    \
                      dim3((unsigned)blocks), dim3(256),                                                               \
@@ -965,6 +980,11 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
         } else {
           t.tp_np = 3;
           t.tp_l[0] = log2n / 3, t.tp_l[1] = (log2n - t.tp_l[0]) / 2, t.tp_l[2] = log2n - t.tp_l[0] - t.tp_l[1];
+        }
+        if (e == hipSuccess) {
+          const std::vector<T2> t8 = build_twiddles<T2>(8);
+          e = hipMalloc((void **)&t.tw8, t8.size() * sizeof(T2));
+          if (e == hipSuccess) e = hipMemcpy(t.tw8, t8.data(), t8.size() * sizeof(T2), hipMemcpyHostToDevice);
         }
         for (int i = 0; i < t.tp_np && e == hipSuccess; ++i) {
           const std::vector<T2> tf = build_twiddles<T2>(t.tp_l[i]);

@@ -2128,6 +2128,109 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
   });
 }
 
+// tile_pass_kernel's ROWS pass for a 512-point factor on tiles of 32 rows.  As a plain tile a 512-point factor
+// fits 16 rows (70 KB of LDS), i.e. 64-byte output segments: 5.0 TB/s per pass, against 6.1 for the 32-row
+// tiles of a 256-point factor (rocprofv3, profiles/r02_experiments/tile_pass_times_per_kernel.csv).  Here the
+// factor is one radix-2 decimation-in-TIME step over two 256-point transforms that the same 256 threads run back
+// to back through the same 70 KB (spectrum_dif16k_kernel's idea, the other way round): a lane's 16-byte loads
+// bring x[p .. p+3] of a row, the even samples go to LDS, the odd ones wait in 64 registers;
+//   E = FFT_256(x[2m]) is read back in OUTPUT layout (four rows per lane, 64 registers), O = FFT_256(x[2m+1])
+//   follows through the same rows, and X[k] = E[k] + W_512^k O[k], X[k + 256] = E[k] - W_512^k O[k]
+// leave as 128-byte segments (32 consecutive rows) at k and k + 256.  Geometry as tile_pass_kernel's ROWS
+// (tiles = rows / 32); tw = radix table of the 256-point transform; W_512^k from the plan's two-level table.
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+tile_rows512_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
+                    const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
+                    const cx<T> *__restrict__ twb, const TileGeom g, const T scale, const long long batch) {
+  using TR = FftTraits<8>;
+  constexpr int L = 512, H = 256, TILE = 32, E = TR::E, TP = TR::TP, RPR = 256 / TP, ROUNDS = TILE / RPR;
+  constexpr int LROWX = TR::LROW + ((2 - TR::LROW % 8) + 8) % 8;
+  constexpr int TS = TILE / 4, SPI = 256 / TS, NIN = TILE * L / 4 / 256, NOUT = H / SPI;  // 16 loads, 8 output rounds
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[TILE * LROWX];
+
+  const int t = (int)threadIdx.x;
+  const long long b = (long long)blockIdx.x / g.tiles;
+  const int t0 = (int)((long long)blockIdx.x % g.tiles) * TILE;
+  if (b >= batch) return;
+  const size_t base = (size_t)b * (size_t)g.n;
+  const int seg = t / TS, j4 = (t % TS) * 4;
+  const int tid = t % TP, rloc = t / TP;
+
+  // tables first: the 256-point transform's bases and W_512^seg (W_512^(seg + 32 ic) = W_512^seg * W_16^ic)
+  RegTwiddles<T, 8> twf;
+  twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  const unsigned m512 = ((unsigned)(g.n >> 9) << g.tshift) * (unsigned)seg;
+  const cx<T> wseg = cmul(twa[m512 >> 9], twb[m512 & 511]);
+
+  // TILE whole rows, one contiguous chunk per plane: lane t, load ic holds points p .. p+3 of row (t >> 7) + 2 ic,
+  // p = 4 (t & 127): even samples 2m, 2m + 2 -> E's inputs m, m + 1 (m = 2 (t & 127)); odd samples -> O's
+  const size_t cbase = base + (size_t)t0 * L;
+  V4 r[NIN], mi[NIN];
+  static_for<NIN>([&](auto ic) {
+    const int e = 4 * (t + 256 * ic);
+    r[ic] = ld_stream(reinterpret_cast<const V4 *>(in_re + cbase + e));
+    mi[ic] = ld_stream(reinterpret_cast<const V4 *>(in_im + cbase + e));
+  });
+  const int me = 2 * (t & 127), lrow0 = t >> 7;
+  cx<T> od[NIN][2];
+  static_for<NIN>([&](auto ic) {
+    cx<T> *const d = lds + (lrow0 + 2 * ic) * LROWX + lds_pad(me);  // me is even: me, me + 1 share a 16-block
+    d[0] = cx<T>{r[ic].x, mi[ic].x};
+    d[1] = cx<T>{r[ic].z, mi[ic].z};
+    od[ic][0] = cx<T>{r[ic].y, mi[ic].y};
+    od[ic][1] = cx<T>{r[ic].w, mi[ic].w};
+  });
+  __syncthreads();
+
+  auto transform_rows = [&]() {
+    static_for<ROUNDS>([&](auto rc) {
+      cx<T> *const lrow = lds + (rc * RPR + rloc) * LROWX;
+      cx<T> x[E];
+      static_for<E>([&](auto q) { x[q] = lrow[lds_pad(tid + TP * q)]; });
+      __syncthreads();  // the first pass scatters into the same rows
+      fft_passes<T, 8, true>(x, lrow, twf, tid);  // natural order in LDS
+    });
+    __syncthreads();
+  };
+  transform_rows();
+  // E in output layout: element (k, j), k = seg + SPI ic, rows j4 .. j4 + 3
+  cx<T> ev[NOUT][4];
+  static_for<NOUT>([&](auto ic) {
+    const cx<T> *const d = lds + j4 * LROWX + lds_pad(seg + SPI * ic);
+    static_for<4>([&](auto jc) { ev[ic][jc] = d[jc * LROWX]; });
+  });
+  __syncthreads();
+  static_for<NIN>([&](auto ic) {
+    cx<T> *const d = lds + (lrow0 + 2 * ic) * LROWX + lds_pad(me);
+    d[0] = od[ic][0];
+    d[1] = od[ic][1];
+  });
+  __syncthreads();
+  transform_rows();
+
+  // row i = j4 + jc, output k goes to out[base + t0 + i + k * out_stride]: 32 consecutive rows = 128-byte segments
+  const size_t obase = base + (size_t)(t0 + j4);
+  static_for<NOUT>([&](auto ic) {
+    constexpr int i = ic;
+    const int k = seg + SPI * i;
+    const cx<T> *const d = lds + j4 * LROWX + lds_pad(k);
+    const cx<T> w = mul_w16<T, i>(wseg);  // W_512^(seg + 32 i)
+    cx<T> lo[4], hi[4];
+    static_for<4>([&](auto jc) {
+      const cx<T> tt = cmul(d[jc * LROWX], w);
+      lo[jc] = (ev[i][jc] + tt) * scale;
+      hi[jc] = (ev[i][jc] - tt) * scale;
+    });
+    const size_t go = obase + (size_t)k * (size_t)g.out_stride, gh = go + (size_t)H * (size_t)g.out_stride;
+    st_stream(V4{lo[0].x, lo[1].x, lo[2].x, lo[3].x}, reinterpret_cast<V4 *>(out_re + go));
+    st_stream(V4{lo[0].y, lo[1].y, lo[2].y, lo[3].y}, reinterpret_cast<V4 *>(out_im + go));
+    st_stream(V4{hi[0].x, hi[1].x, hi[2].x, hi[3].x}, reinterpret_cast<V4 *>(out_re + gh));
+    st_stream(V4{hi[0].y, hi[1].y, hi[2].y, hi[3].y}, reinterpret_cast<V4 *>(out_im + gh));
+  });
+}
+
 // The tail of the packed-real long-frame spectrum path: Z = the M-point transform (natural order, planar)
 // of z[m] = x[2m] + i x[2m+1], M = N/2.  One lane takes the pair (k, M - k), 0 <= k <= M/2:
 //   X[k]     =      (Z[k] + conj(Z[M-k])) / 2 - i W_N^k (Z[k] - conj(Z[M-k])) / 2

@@ -170,7 +170,10 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
             pdsp.lib.pdsp_set_twopass(prev)
         res[mode] = got
     assert rel_err(res[1], res[0]) <= 2e-6
-    assert np.array_equal(res[1], res[3])                 # the same arithmetic, another scratch layout
+    if log2n in (17,):                                    # a 512-point last factor: tile_rows512_kernel vs plain tiles
+        assert rel_err(res[1], res[3]) <= 2e-6
+    else:
+        assert np.array_equal(res[1], res[3])             # the same arithmetic, another scratch layout
 
 
 @pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20, 21, 22, 24])
@@ -214,7 +217,9 @@ def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_m
                 d = np.abs((ph.cpu().numpy() - wph + np.pi) % (2 * np.pi) - np.pi)
                 assert d[mask].max() <= 2e-3
                 res[mode] = a
-            assert rel_err(res[1], res[0]) <= 2e-6 and np.array_equal(res[1], res[3])
+            assert rel_err(res[1], res[0]) <= 2e-6
+            # the half-size transform of 2^18-sample frames ends in a 512-point factor (tile_rows512_kernel)
+            assert rel_err(res[1], res[3]) <= 2e-6 if log2n == 18 else np.array_equal(res[1], res[3])
     idx, freq, a, p, _, _ = plan.spectrum_peaks(dx, "hann", "one", 48000.0)
     assert [int(v) for v in idx.cpu()] == [tone] * 3
     short = torch.from_numpy(x[:, : n - 1000].copy()).cuda()          # zero-padded frames: four-step form
