@@ -501,6 +501,22 @@ int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *
   if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
   const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
   const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
+  if constexpr (COLS && sizeof(T) == 4) {
+    // a 512-point factor as a column pass: 32-column tiles through tile_cols512_kernel (128-byte strided segments)
+    // instead of 16-column ones; pdsp_set_twopass bit 1 keeps the plain tiles (A/B tests)
+    if (l == 9 && real_in <= 1 && t.tw8 && !(g_twopass & 2) && g.tiles % 2 == 0) {
+      g.tiles /= 2;
+      const long long wide = batch * g.nblk * g.tiles;
+      if (real_in == 1)
+        hipLaunchKernelGGL((pdsp::tile_cols512_kernel<T, 1>), dim3((unsigned)wide), dim3(256), 0, s, in_re, in_im, out_re,
+                           out_im, t.tw8, twa, twb, g, batch);
+      else
+        hipLaunchKernelGGL((pdsp::tile_cols512_kernel<T, 0>), dim3((unsigned)wide), dim3(256), 0, s, in_re, in_im, out_re,
+                           out_im, t.tw8, twa, twb, g, batch);
+      PDSP_HIP_TRY(hipGetLastError());
+      return PDSP_OK;
+    }
+  }
   if constexpr (!COLS && sizeof(T) == 4) {
     // a 512-point factor as the last pass: 32-row tiles through tile_rows512_kernel (128-byte output segments)
     // instead of 16-row ones; pdsp_set_twopass bit 1 keeps the plain tiles (A/B tests)
@@ -543,7 +559,7 @@ int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *
 }
 constexpr int tile_width(int l) { return l == 6 ? 64 : (l == 9 ? 16 : 32); }
 
-// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27 (not 2^18), f32, 16-byte aligned
+// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27, f32, 16-byte aligned
 // planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
 // pass reads one pair and writes another, so input and output may alias each other.
 // `window` (real input only): applyWindow on the first pass's load; in_batch: distance between input rows.
@@ -577,7 +593,8 @@ int tilepass_chain(const Tables<T> &t, long long n, int np, const int *l, typena
   if (!(g_twopass & 2)) {
     // the scratch planes between the first two passes tile-major (TileGeom::perm_*): the second pass reads its
     // [B][TILE] tiles as contiguous chunks; pdsp_set_twopass bit 1 keeps them in natural order (A/B tests)
-    const int lt = l[1] == 6 ? 6 : (l[1] == 9 ? 4 : 5);  // log2 tile_width(l[1])
+    // log2 of the second pass's tile width (512-point columns: 32 on tile_cols512_kernel, which this mode implies)
+    const int lt = l[1] == 6 ? 6 : ((l[1] == 9 && !(sizeof(T) == 4 && t.tw8)) ? 4 : 5);
     g1.perm_lc = l[2], g1.perm_lt = lt, g1.perm_b = (int)b;
     g2.in_tile = b << lt, g2.in_stride = 1LL << lt;
   }
@@ -588,7 +605,7 @@ int tilepass_chain(const Tables<T> &t, long long n, int np, const int *l, typena
   return tile_pass<T, false>(l[2], 0, (const T *)s2_re, (const T *)s2_im, re_out, im_out, tw[2], t, g3, scale, batch, s);
 }
 
-// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27 (not 2^18), f32, 16-byte aligned
+// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27, f32, 16-byte aligned
 // planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
 // pass reads one pair and writes another, so input and output may alias each other.
 // `window` (real input only): applyWindow on the first pass's load; in_batch: distance between input rows.
@@ -974,7 +991,7 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
       // tile passes, balanced factors (tile_pass_kernel's header), ascending so that the widest tiles
       // serve the passes with two strided streams
       if (e == hipSuccess && sizeof(T) == 4 && log2n >= 15 && log2n <= 27) {
-        if (log2n <= 17) {
+        if (log2n <= 18) {  // 2^18 = 512 * 512: both factors on 32-wide tiles (tile_cols512_kernel, tile_rows512_kernel)
           t.tp_np = 2;
           t.tp_l[0] = log2n / 2, t.tp_l[1] = log2n - t.tp_l[0];
         } else {

@@ -2128,6 +2128,130 @@ tile_pass_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__
   });
 }
 
+// tile_pass_kernel's COLS pass for a 512-point factor on tiles of 32 columns (plain tiles: 16 columns, 64-byte
+// strided segments -- the width at which the memory system collapses, tools/kbench3).  One radix-2
+// decimation-in-FREQUENCY step over two 256-point halves that the same 256 threads run back to back through the
+// same 70 KB of LDS: a lane loads x[p] and x[p + 256] of its four columns, u[p] = x[p] + x[p + 256] goes to LDS,
+// v[p] = (x[p] - x[p + 256]) W_512^p waits in 64 registers; FFT_256(u) = the even output rows k1 = 2k,
+// FFT_256(v) = the odd ones k1 = 2k + 1.  Geometry (tiles = columns / 32), the tile-major scratch options and the
+// inter-pass twiddles W_N^(tmul col k1) (hoisted two-level lookups) as tile_pass_kernel's COLS; IN = 0 complex
+// planes, 1 real rows.  tw = radix table of the 256-point transform.
+template <typename T, int IN>
+__global__ void __launch_bounds__(256, 2)
+tile_cols512_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
+                    const typename vec2<T>::type *__restrict__ tw, const cx<T> *__restrict__ twa,
+                    const cx<T> *__restrict__ twb, const TileGeom g, const long long batch) {
+  static_assert(IN == 0 || IN == 1, "complex planes or real rows");
+  constexpr bool REAL_IN = IN == 1;
+  using TR = FftTraits<8>;
+  constexpr int TILE = 32, H = 256, E = TR::E, TP = TR::TP, RPR = 256 / TP, ROUNDS = TILE / RPR;
+  constexpr int LROWX = TR::LROW + ((2 - TR::LROW % 8) + 8) % 8;
+  constexpr int TS = TILE / 4, SPI = 256 / TS, NIT = H / SPI;  // 8 lanes per segment, 32 rows per access, 8 accesses
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[TILE * LROWX];
+
+  const int t = (int)threadIdx.x;
+  const long long per = (long long)g.nblk * g.tiles;
+  const long long b = (long long)blockIdx.x / per;
+  const int rem = (int)((long long)blockIdx.x % per);
+  const int blk = rem / g.tiles, t0 = (rem % g.tiles) * TILE;
+  if (b >= batch) return;
+  const size_t base = (size_t)b * (size_t)g.n;
+  const int seg = t / TS, j4 = (t % TS) * 4;
+  const int tid = t % TP, rloc = t / TP;
+
+  // tables first.  Output row k1 = 2 (seg + SPI ic) + o (o = 0: even half, 1: odd half); q = tmul << tshift, J = t0 + j4:
+  //   first column of the lane's four: W^(q J k1) = W^(q J 2 seg) * (W^(q J 2 SPI))^ic   [* W^(q J) for o = 1]
+  //   step to the next column:         W^(q k1)   = W^(q 2 seg)   * (W^(q 2 SPI))^ic     [* W^q     for o = 1]
+  RegTwiddles<T, 8> twf;
+  twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+  const unsigned q = g.tmul << g.tshift, J = (unsigned)(t0 + j4);
+  auto look = [&](unsigned m) { return cmul(twa[m >> 9], twb[m & 511]); };
+  const cx<T> w_first0 = look(q * J * (unsigned)(2 * seg)), w_first_step = look(q * J * (unsigned)(2 * SPI));
+  const cx<T> w_col0 = look(q * (unsigned)(2 * seg)), w_col_step = look(q * (unsigned)(2 * SPI));
+  const cx<T> w_odd_first = look(q * J), w_odd_col = look(q);
+  const cx<T> ws = look(((unsigned)(g.n >> 9) << g.tshift) * (unsigned)seg);  // W_512^seg; W_512^(seg + 32 ic) = ws W_16^ic
+  cx<T> wv[NIT];
+  static_for<NIT>([&](auto ic) {
+    constexpr int i = ic;
+    wv[i] = mul_w16<T, i>(ws);
+  });
+
+  // strided tile in: rows p and p + 256 of the lane's four columns; every load first
+  const size_t in_off = (size_t)blk * (size_t)g.in_blk +
+                        (g.in_tile ? (size_t)(t0 / TILE) * (size_t)g.in_tile + (size_t)j4 : (size_t)(t0 + j4));
+  const size_t ibase = (size_t)b * (size_t)g.in_batch + in_off;
+  V4 ra[NIT], ma[NIT], rb[NIT], mb[NIT];
+  static_for<NIT>([&](auto ic) {
+    const size_t gi = ibase + (size_t)(seg + SPI * ic) * (size_t)g.in_stride, gj = gi + (size_t)H * (size_t)g.in_stride;
+    ra[ic] = ld_stream(reinterpret_cast<const V4 *>(in_re + gi));
+    rb[ic] = ld_stream(reinterpret_cast<const V4 *>(in_re + gj));
+    if constexpr (!REAL_IN) {
+      ma[ic] = ld_stream(reinterpret_cast<const V4 *>(in_im + gi));
+      mb[ic] = ld_stream(reinterpret_cast<const V4 *>(in_im + gj));
+    }
+  });
+  cx<T> v[NIT][4];
+  static_for<NIT>([&](auto ic) {
+    const V4 z = V4{T(0), T(0), T(0), T(0)};
+    const V4 r1 = ra[ic], r2 = rb[ic], m1 = REAL_IN ? z : ma[ic], m2 = REAL_IN ? z : mb[ic];
+    const cx<T> a[4] = {cx<T>{r1.x, m1.x}, cx<T>{r1.y, m1.y}, cx<T>{r1.z, m1.z}, cx<T>{r1.w, m1.w}};
+    const cx<T> c[4] = {cx<T>{r2.x, m2.x}, cx<T>{r2.y, m2.y}, cx<T>{r2.z, m2.z}, cx<T>{r2.w, m2.w}};
+    cx<T> *const d = lds + j4 * LROWX + lds_pad(seg + SPI * ic);
+    static_for<4>([&](auto jc) {
+      v[ic][jc] = cmul(a[jc] - c[jc], wv[ic]);
+      d[jc * LROWX] = a[jc] + c[jc];
+    });
+  });
+  __syncthreads();
+
+  size_t ocol = (size_t)(t0 + j4);
+  if (g.perm_lt) {  // tile-major scratch (TileGeom)
+    const unsigned np = (unsigned)(t0 + j4), n2 = np >> g.perm_lc, n3 = np & ((1u << g.perm_lc) - 1u);
+    ocol = ((size_t)((n3 >> g.perm_lt) * (unsigned)g.perm_b + n2) << g.perm_lt) | (size_t)(n3 & ((1u << g.perm_lt) - 1u));
+  }
+  const size_t obase = base + (size_t)blk * (size_t)g.out_blk + ocol;
+  static_for<2>([&](auto oc) {
+    constexpr int o = oc;
+    if constexpr (o == 1) {  // the odd half: v from the registers into the same rows
+      __syncthreads();       // (the even half's tile has been read out)
+      static_for<NIT>([&](auto ic) {
+        cx<T> *const d = lds + j4 * LROWX + lds_pad(seg + SPI * ic);
+        static_for<4>([&](auto jc) { d[jc * LROWX] = v[ic][jc]; });
+      });
+      __syncthreads();
+    }
+    static_for<ROUNDS>([&](auto rc) {
+      cx<T> *const lrow = lds + (rc * RPR + rloc) * LROWX;
+      cx<T> x[E];
+      static_for<E>([&](auto qq) { x[qq] = lrow[lds_pad(tid + TP * qq)]; });
+      __syncthreads();  // the first pass scatters into the same rows
+      fft_passes<T, 8, true>(x, lrow, twf, tid);  // natural order in LDS
+    });
+    __syncthreads();
+    // strided tile out: element (k, j) -> out[... + (2 k + o) * out_stride + j], times W_N^(tmul col k1)
+    cx<T> tw_w = o == 1 ? cmul(w_first0, w_odd_first) : w_first0, tw_s = o == 1 ? cmul(w_col0, w_odd_col) : w_col0;
+    static_for<NIT>([&](auto ic) {
+      const int k1 = 2 * (seg + SPI * ic) + o;
+      const cx<T> *const d = lds + j4 * LROWX + lds_pad(seg + SPI * ic);
+      cx<T> y[4] = {d[0 * LROWX], d[1 * LROWX], d[2 * LROWX], d[3 * LROWX]};
+      cx<T> w = tw_w;
+      y[0] = cmul(y[0], w);
+      static_for<3>([&](auto jc) {
+        w = cmul(w, tw_s);
+        y[jc + 1] = cmul(y[jc + 1], w);
+      });
+      if constexpr (ic + 1 < NIT) {
+        tw_w = cmul(tw_w, w_first_step);
+        tw_s = cmul(tw_s, w_col_step);
+      }
+      const size_t go = obase + (size_t)k1 * (size_t)g.out_stride;
+      st_stream(V4{y[0].x, y[1].x, y[2].x, y[3].x}, reinterpret_cast<V4 *>(out_re + go));
+      st_stream(V4{y[0].y, y[1].y, y[2].y, y[3].y}, reinterpret_cast<V4 *>(out_im + go));
+    });
+  });
+}
+
 // tile_pass_kernel's ROWS pass for a 512-point factor on tiles of 32 rows.  As a plain tile a 512-point factor
 // fits 16 rows (70 KB of LDS), i.e. 64-byte output segments: 5.0 TB/s per pass, against 6.1 for the 32-row
 // tiles of a 256-point factor (rocprofv3, profiles/r02_experiments/tile_pass_times_per_kernel.csv).  Here the

@@ -130,8 +130,7 @@ def test_general_four_step_n_2_24(oracle_mod):
 @pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
 def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
     """f32 transforms beyond the single-pass limit on tile_pass_kernel -- balanced factors, two passes over
-    HBM for 2^15 <= N <= 2^17 and three for 2^19 <= N <= 2^27 (2^18 stays on the four-step form either
-    way), the scratch planes between the first two of three passes tile-major (default) and in natural order
+    HBM for 2^15 <= N <= 2^18 and three for 2^19 <= N <= 2^27, the scratch planes between the first two of three passes tile-major (default) and in natural order
     (pdsp_set_twopass(3): bit-identical results) -- against round 1's four-step forms (pdsp_set_twopass(0): three / five passes) and the oracle:
     complex, real input, inverse, an in-place call (output planes = input planes) and an odd batch."""
     import torch
@@ -170,7 +169,7 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
             pdsp.lib.pdsp_set_twopass(prev)
         res[mode] = got
     assert rel_err(res[1], res[0]) <= 2e-6
-    if log2n in (17,):                                    # a 512-point last factor: tile_rows512_kernel vs plain tiles
+    if log2n in (17, 18):                                 # 512-point factors: tile_rows512 / tile_cols512_kernel vs plain tiles
         assert rel_err(res[1], res[3]) <= 2e-6
     else:
         assert np.array_equal(res[1], res[3])             # the same arithmetic, another scratch layout
