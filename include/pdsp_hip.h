@@ -158,7 +158,9 @@ PDSP_API int pdsp_plan_destroy(pdsp_plan *plan);
 PDSP_API long long pdsp_plan_size(const pdsp_plan *plan);
 /* pdsp_spectrum_host_f64 keeps its plans and device windows in a process-wide cache keyed
  * by (size, device) -- the FourierLive idea, src/effect/index.ts:30-48 (the reference's
- * spectrum() rebuilds plan and window on every call, spectrum.ts:114-116).  This frees it. */
+ * spectrum() rebuilds plan and window on every call, spectrum.ts:114-116).  This frees it, and hands the
+ * scratch planes the multi-pass paths (N > 16384) keep in the engine's own stream-ordered memory pool -- as large
+ * as the largest such transform run so far -- back to the device. */
 PDSP_API int pdsp_plan_cache_clear(void);
 PDSP_API int pdsp_plan_device(const pdsp_plan *plan);
 

@@ -49,13 +49,50 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 // Stream-ordered scratch that is handed back on every exit path.
+// Stream-ordered scratch planes of the multi-pass paths, from a pool of the engine's own per device whose release
+// threshold is unlimited: the device's default pool hands its memory back at every synchronisation, so that a
+// caller who synchronises between transforms (every host-f64 call does) paid a fresh 1-2 GiB allocation --
+// a trip through the kernel driver, observed to stall for 0.5-1 s on a busy host -- on each call.  Here the planes
+// of the largest transform seen stay with the engine until pdsp_plan_cache_clear() trims the pools.
+constexpr int kMaxPoolDevices = 64;
+hipMemPool_t g_scratch_pool[kMaxPoolDevices] = {};
+std::mutex g_scratch_pool_mu;
+hipMemPool_t scratch_pool() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxPoolDevices) return nullptr;
+  std::lock_guard<std::mutex> lk(g_scratch_pool_mu);
+  if (!g_scratch_pool[dev]) {
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    uint64_t keep = ~0ULL;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    g_scratch_pool[dev] = pool;
+  }
+  return g_scratch_pool[dev];
+}
+void trim_scratch_pools() {
+  std::lock_guard<std::mutex> lk(g_scratch_pool_mu);
+  for (hipMemPool_t pool : g_scratch_pool)
+    if (pool) (void)hipMemPoolTrimTo(pool, 0);
+}
+
 struct StreamScratch {
   void *p = nullptr;
   hipStream_t s;
   explicit StreamScratch(hipStream_t stream) : s(stream) {}
   StreamScratch(const StreamScratch &) = delete;
   StreamScratch &operator=(const StreamScratch &) = delete;
-  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes, s); }
+  hipError_t alloc(size_t bytes) {
+    if (hipMemPool_t pool = scratch_pool()) return hipMallocFromPoolAsync(&p, bytes, pool, s);
+    return hipMallocAsync(&p, bytes, s);  // no pool of our own on this device: the default one
+  }
   ~StreamScratch() {
     if (p) (void)hipFreeAsync(p, s);
   }
@@ -208,6 +245,14 @@ std::vector<T2> build_twiddles(int log2n, int log2e = 4) {
       }
   }
   return tw;
+}
+
+// Factors of a three-pass transform of 2^lg points (2^18 < 2^lg <= 2^27): balanced, ascending.  (Tried and
+// dropped: a 64-point first factor everywhere -- the widest tiles for the one pass that reads strided -- with
+// 512-point factors behind it: 2^22 as 64 * 256 * 256 and 2^24 as 64 * 512 * 512 measured -3 % / +1 % against
+// 128 * 128 * 256 and 256^3, the long-frame spectrum -2 ... -5 %: profiles/r02_experiments/sweep_large_factors.log.)
+inline void three_factors(int lg, int *l) {
+  l[0] = lg / 3, l[1] = (lg - l[0]) / 2, l[2] = lg - l[0] - l[1];
 }
 
 template <typename T, int LOG2N, class LD, class ST>
@@ -996,7 +1041,7 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
           t.tp_l[0] = log2n / 2, t.tp_l[1] = log2n - t.tp_l[0];
         } else {
           t.tp_np = 3;
-          t.tp_l[0] = log2n / 3, t.tp_l[1] = (log2n - t.tp_l[0]) / 2, t.tp_l[2] = log2n - t.tp_l[0] - t.tp_l[1];
+          three_factors(log2n, t.tp_l);
         }
         if (e == hipSuccess) {
           const std::vector<T2> t8 = build_twiddles<T2>(8);
@@ -1008,14 +1053,15 @@ hipError_t upload_tables(Tables<T> &t, int log2n, long long size, bool full, boo
           e = hipMalloc((void **)&t.tp_tw[i], tf.size() * sizeof(T2));
           if (e == hipSuccess) e = hipMemcpy(t.tp_tw[i], tf.data(), tf.size() * sizeof(T2), hipMemcpyHostToDevice);
         }
-        // the N/2-point transform of the packed-real spectrum path: 2^14 ... 2^17 in two factors, above in three
+        // the N/2-point transform of the packed-real spectrum path: 2^14 ... 2^18 in two factors (2^18 = 512 * 512:
+        // the packed first pass on 16-column tiles still reads 128-byte segments, eight samples per lane), above in three
         const int lm = log2n - 1;
-        if (lm <= 17) {
+        if (lm <= 18) {
           t.hp_np = 2;
           t.hp_l[0] = lm / 2, t.hp_l[1] = lm - t.hp_l[0];
         } else {
           t.hp_np = 3;
-          t.hp_l[0] = lm / 3, t.hp_l[1] = (lm - t.hp_l[0]) / 2, t.hp_l[2] = lm - t.hp_l[0] - t.hp_l[1];
+          three_factors(lm, t.hp_l);
         }
         for (int i = 0; i < t.hp_np && e == hipSuccess; ++i) {
           const std::vector<T2> tf = build_twiddles<T2>(t.hp_l[i]);
@@ -1707,6 +1753,7 @@ int pdsp_plan_cache_clear(void) {
       ++it;
     }
   }
+  trim_scratch_pools();  // the multi-pass paths' scratch planes (StreamScratch) go back to the device
   return PDSP_OK;
 }
 
