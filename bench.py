@@ -129,6 +129,51 @@ def traffic_from_profile(kernel_substr: str):
     return None
 
 
+def traffic_measured(args, kernel_substr: str):
+    """HBM bytes per launch of the workload's kernel, measured now: this workload again, a few steps, as a CHILD
+    process under `rocprofv3 --pmc FETCH_SIZE` and once more under `--pmc WRITE_SIZE` (separate passes, counters
+    only -- no trace domain beside them), reduced as MI355X_MICROARCH.md's HBM section prescribes: both counters
+    are in KiB, and on gfx950 FETCH_SIZE reports half of a wide coalesced streaming read, so it is doubled.
+    Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "3", "--warmup", "1",
+             "--ramp-seconds", "0", "--no-cpu-baseline", "--no-also", "--chunk", str(args.chunk)]
+    if args.batch is not None:
+        child += ["--batch", str(args.batch)]
+    elif args.workload in ("spectrum16k", "peaks16k"):
+        child += ["--batch", str(4 * args.chunk)]  # a few chunks are enough for a per-launch average
+    if args.n is not None:
+        child += ["--n", str(args.n)]
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="pdsp_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PDSP_BENCH_PMC_CHILD="1"), capture_output=True, text=True,
+                               timeout=180)
+            vals = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if p.returncode != 0 or not vals:
+                return None, f"{counter} pass: rc {p.returncode}, {len(vals)} samples: {(p.stderr or '')[-200:]}"
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+            return None, f"{counter} pass: {type(exc).__name__}: {exc}"[:300]
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    rd, wr = got["FETCH_SIZE"][0] * 1024 * 2, got["WRITE_SIZE"][0] * 1024
+    return rd + wr, {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "launches_sampled": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]]}
+
+
 def single_frame_latency(args, dev) -> int:
     """BASELINE configs[1]: ONE N=1024 real frame, Hann window, forward FFT, magnitude.
     Latency-bound (8 KiB of traffic): reported as microseconds, not as a roofline fraction.
@@ -380,6 +425,11 @@ def parse_args(argv):
     ap.add_argument("--gather", action="store_true", help="(default at --gpus > 1; kept for older command lines)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the RCCL all-gather of the output slabs and of the peak records (timed on its own, after the timed region)")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="N = 1: measure roofline.traffic in this run -- two child runs of this workload under "
+                         "`rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE; ~20 s) -- instead of quoting profiles/traffic.json; "
+                         "default for the default workload unless this process itself runs under a profiler")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="quote profiles/traffic.json (the committed PMC pass)")
     ap.add_argument("--gather-timeout", type=float, default=150.0,
                     help="N > 1: seconds the exchange leg may take before the line is printed without it")
     ap.add_argument("--dry-run", action="store_true",
@@ -387,6 +437,11 @@ def parse_args(argv):
     ap.add_argument("--fail-rank", type=int, default=-1, help="testing the launcher: this rank exits with status 3")
     ap.add_argument("--launch-timeout", type=float, default=900.0)
     args = ap.parse_args(argv)
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if args.no_measure_traffic or under_profiler or os.environ.get("PDSP_BENCH_PMC_CHILD"):
+        args.measure_traffic = False
+    elif args.workload == "fft4096" and args.batch is None and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
+        args.measure_traffic = True
     if args.dist_backend is None:
         args.dist_backend = "gloo" if (args.share_gpu or args.dry_run) else "nccl"
     return args
@@ -658,6 +713,15 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                        "device_copy_under_load": copy_clocks,
                        "source": "sysfs pp_dpm_* and hwmon of /sys/class/drm/card*/device"},
         }
+        if args.measure_traffic and world == 1:
+            nbytes, detail = traffic_measured(args, kernel_name)
+            if nbytes is not None:
+                out["roofline"]["traffic"] = nbytes
+                out["roofline"]["traffic_detail"] = detail
+                out["roofline"]["traffic_source"] = ("measured in this run: two child runs of this workload under rocprofv3 --pmc "
+                                                     "(FETCH_SIZE KiB x 1024 x 2 on gfx950, WRITE_SIZE KiB x 1024), averaged per launch")
+            else:
+                out["roofline"]["traffic_measure_error"] = detail
         if world > 1:
             out["per_rank_kernel_ms"] = per_rank_ms
             # each rank's own kernel against ITS card's HBM peak, and the whole job against world x peak
