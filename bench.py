@@ -157,7 +157,7 @@ def traffic_measured(args, kernel_substr: str):
         try:
             p = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--"] + child,
                                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PDSP_BENCH_PMC_CHILD="1"), capture_output=True, text=True,
-                               timeout=180)
+                               timeout=60)
             vals = []
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
