@@ -175,6 +175,40 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
         assert np.array_equal(res[1], res[3])             # the same arithmetic, another scratch layout
 
 
+@pytest.mark.parametrize("log2n", [26, 27])
+def test_tile_passes_with_512_point_column_factors(pdsp, log2n):
+    """2^26 = 256 * 512 * 512 and 2^27 = 512^3: the sizes whose FIRST / MIDDLE passes are 512-point column factors
+    (tile_cols512_kernel, reading tile-major scratch in the middle) -- one row, forward and in-place inverse, against
+    the first form of the tile passes (pdsp_set_twopass(3)), round 1's four-step form (0: an independent
+    factorisation) and numpy's f64 transform.  The C oracle is not run at these sizes (minutes); numpy.fft is
+    not reference-pinned, the four-step form is pinned at the smaller sizes above."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n = 1 << log2n
+    rng = np.random.default_rng(300 + log2n)
+    re = rng.standard_normal((1, n)).astype(np.float32)
+    im = rng.standard_normal((1, n)).astype(np.float32)
+    want = np.fft.fft(re[0].astype(np.float64) + 1j * im[0].astype(np.float64))
+    plan = BatchedFft(n, "cuda:0")
+    dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
+    res = {}
+    for mode in (1, 3, 0):
+        prev = pdsp.lib.pdsp_set_twopass(mode)
+        try:
+            ore, oim = plan.forward(dre, dim)
+            res[mode] = ore[0].cpu().numpy().astype(np.float64) + 1j * oim[0].cpu().numpy()
+            if mode == 1:
+                plan.inverse(ore, oim, out=(ore, oim))   # in place
+                torch.cuda.synchronize()
+                assert np.abs(ore[0].cpu().numpy() - re[0]).max() <= 4e-5 * np.abs(re).max()
+                assert np.abs(oim[0].cpu().numpy() - im[0]).max() <= 4e-5 * np.abs(im).max()
+        finally:
+            pdsp.lib.pdsp_set_twopass(prev)
+    top = np.abs(want).max()
+    assert np.abs(res[1] - want).max() <= 1e-5 * top
+    assert np.abs(res[1] - res[3]).max() <= 2e-6 * top and np.abs(res[1] - res[0]).max() <= 2e-6 * top
+
+
 @pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20, 21, 22, 24])
 def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
     """spectrum() of frames longer than the single-pass limit (whole 16-byte aligned f32 frames): the packed-real
