@@ -112,12 +112,12 @@ PDSP_API int pdsp_set_staged_small(int enabled);
  * previous value. */
 PDSP_API int pdsp_set_fused_window(int enabled);
 /* 1 (default): f32 transforms of 2^15 <= N <= 2^27 on 16-byte aligned planes run as tile passes over
- * balanced factors of 64 ... 512 points (tile_pass_kernel): TWO passes over HBM up to 2^17, THREE above;
+ * balanced factors of 64 ... 512 points (tile_pass_kernel): TWO passes over HBM up to 2^18, THREE above;
  * 0: round 1's four-step forms (N1 <= 16 columns, 16384-point rows, transposing copy: three passes up to
  * 2^18, five above); 3: tile passes in their first form -- the scratch planes between the first two of three
- * passes in natural order instead of tile-major (bit-identical results), a 512-point last factor on 16-row
- * tiles instead of tile_rows512_kernel's 32 (same results within rounding).  A/B switch, returns the previous
- * value. */
+ * passes in natural order instead of tile-major (bit-identical results), 512-point factors on 16-wide tiles
+ * instead of the 32-wide ones of tile_rows512_kernel / tile_cols512_kernel (same results within rounding).
+ * A/B switch, returns the previous value. */
 PDSP_API int pdsp_set_twopass(int enabled);
 
 /* Arithmetic of the *_host_f64 entry points (process-wide; returns the previous value).
