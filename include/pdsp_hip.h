@@ -117,6 +117,8 @@ PDSP_API int pdsp_set_fused_window(int enabled);
  * 2^18, five above); 3: tile passes in their first form -- the scratch planes between the first two of three
  * passes in natural order instead of tile-major (bit-identical results), 512-point factors on 16-wide tiles
  * instead of the 32-wide ones of tile_rows512_kernel / tile_cols512_kernel (same results within rounding).
+ * With the value 1 only, 2^15 and 2^16 out of place run in ONE pass over HBM on fft_paired_kernel (2 / 4 sibling
+ * workgroups per transform sharing an XCD's L2); 5 = the tile passes' current form without it.
  * A/B switch, returns the previous value. */
 PDSP_API int pdsp_set_twopass(int enabled);
 

@@ -677,6 +677,36 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
   if constexpr (sizeof(T) == 4) {
+    // N = 2^15 / 2^16 out of place: ONE pass over HBM by 2 / 4 sibling workgroups per transform that share their
+    // XCD's L2 (fft_paired_kernel).  In place the siblings would overwrite each other's input: tile passes then.
+    // pdsp_set_twopass: any value but 1 keeps the tile passes (5: their current form) -- A/B tests.
+    if ((plan->log2n == 15 || plan->log2n == 16) && g_twopass == 1 && t.tw12 && t.tws4 && t.twa && t.twb &&
+        (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {
+      const size_t plane_bytes = (size_t)batch * (size_t)plan->n * sizeof(T);
+      auto overlaps = [&](const T *a, const T *b) {
+        return a && b && (const char *)a < (const char *)b + plane_bytes && (const char *)b < (const char *)a + plane_bytes;
+      };
+      if (!overlaps(re_in, re_out) && !overlaps(re_in, im_out) && !overlaps(im_in, re_out) && !overlaps(im_in, im_out)) {
+        const int lp = plan->log2n - 14;
+        const long long blocks = ((batch + 7) / 8) * 8 * (1LL << lp);
+        if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
+        const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
+        const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
+#define PDSP_PAIRED(LP, REAL)                                                                                        \
+  hipLaunchKernelGGL((pdsp::fft_paired_kernel<T, LP, REAL>), dim3((unsigned)blocks), dim3(256), 0, s, re_in, im_in, re_out, \
+                     im_out, t.tw12, t.tws4, twa, twb, scale, batch)
+        if (lp == 1) {
+          if (im_in) PDSP_PAIRED(1, false);
+          else PDSP_PAIRED(1, true);
+        } else {
+          if (im_in) PDSP_PAIRED(2, false);
+          else PDSP_PAIRED(2, true);
+        }
+#undef PDSP_PAIRED
+        PDSP_HIP_TRY(hipGetLastError());
+        return PDSP_OK;
+      }
+    }
     // tile passes with balanced factors (two for 2^15..2^17, three for 2^19..2^27) where the tables exist and
     // every plane is 16-byte aligned; pdsp_set_twopass(0) keeps round 1's four-step forms (A/B tests)
     if (t.tp_np && (g_twopass & 1) &&
@@ -1593,7 +1623,7 @@ int pdsp_set_split16k(int enabled) {
 
 int pdsp_set_twopass(int enabled) {
   const int prev = g_twopass;
-  g_twopass = enabled & 3;  // bit 0: tile passes; bit 1: natural-order scratch between the first two of three
+  g_twopass = enabled & 7;  // bit 0: tile passes; bit 1: their first form; bit 2 (or any value but 1): no fft_paired_kernel
   return prev;
 }
 

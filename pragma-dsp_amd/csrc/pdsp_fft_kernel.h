@@ -1596,6 +1596,106 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   });
 }
 
+// N = P * 16384 (P = 2, 4) in ONE pass over HBM, by workgroups that are siblings in one XCD's L2.
+// Decimation in frequency by P in front of fft_split4_kernel's body: with S = 16384 and n < S,
+//   y_h[n] = W_N^(h n) * sum_{p < P} x[n + p S] W_P^(p h),        X[P k + h] = FFT_S(y_h)[k],     h < P,
+// so transform t is P independent 16384-point transforms -- P workgroups -- each of which reads ALL of x (P
+// contiguous segments of S points) and writes every P-th output.  Taken alone that is P times the read traffic
+// and partial-line writes; but an XCD's workgroups share its 4 MiB L2, and the dispatcher deals workgroup ids
+// round-robin to the eight XCDs: sibling h of transform t sits at blockIdx (t / 8) * 8 P + 8 h + (t % 8), so the
+// P siblings have the same id mod 8 -- the same XCD -- and leave the dispatcher one round apart.  They run the
+// same instruction stream over the same addresses: the first sibling's loads bring a line into that L2, the others
+// hit it; each line of the output is completed there by the P siblings' stores before it is written back.  HBM
+// then sees 8 B read + 8 B written per sample -- one pass -- where the tile passes make two (32 B).
+// (If the dispatcher did not pair them the results would still be right: every workgroup is self-sufficient.)
+//   tw12 = radix table of the 4096-point transform; tws[k] = W_16384^k, k < 768 (fft_split4_kernel's);
+//   W_N^m = twa[m >> 9] * twb[m & 511]; REAL: Radix2Fft.forward rows (no imaginary plane).
+template <typename T, int LOG2P, bool REAL>
+__global__ void __launch_bounds__(256, 2)
+fft_paired_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
+                  const typename vec2<T>::type *__restrict__ tw12, const typename vec2<T>::type *__restrict__ tws,
+                  const cx<T> *__restrict__ twa, const cx<T> *__restrict__ twb, const T scale, const long long batch) {
+  using TR = FftTraits<12>;
+  constexpr int E = 16, TP = 256, H = 4096, S = 4 * H, P = 1 << LOG2P, N = P * S;
+  static_assert(LOG2P == 1 || LOG2P == 2, "two or four siblings");
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ cx<T> lds[TR::LROW];
+
+  const int tid = (int)threadIdx.x;
+  const unsigned blk = (unsigned)__builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  const long long t = (long long)(blk / (8u * P)) * 8 + (blk & 7u);
+  const unsigned h = (blk >> 3) & (unsigned)(P - 1);
+  if (t >= batch) return;
+
+  RegTwiddles<T, 12> twf;
+  twf.load(reinterpret_cast<const cx<T> *>(tw12), tid);
+  const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
+  const cx<T> w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
+  // W_N^(h n), n = 4 (tid + 256 q) + j:  wt[j] = W_N^(h (4 tid + j)) per thread, wq = W_N^(1024 h q) per q (wave-uniform)
+  auto look = [&](unsigned m) { return cmul(twa[m >> 9], twb[m & 511]); };
+  cx<T> wt[4];
+  static_for<4>([&](auto j) { wt[j] = look(h * (unsigned)(4 * tid + j)); });
+  load_order_fence();
+
+  const size_t base = (size_t)t * (size_t)N;
+  cx<T> a[E], b[E], c[E], d[E];
+  static_for<E>([&](auto qc) {
+    constexpr int q = qc;
+    cx<T> x[P][4];
+    static_for<P>([&](auto pc) {
+      const size_t o = base + (size_t)pc * S + 4 * (size_t)(TP * q + tid);
+      // plain (not non-temporal) accesses on both sides: the siblings' reuse lives in the XCD's L2
+      const V4 r = *reinterpret_cast<const V4 *>(in_re + o);
+      V4 m = V4{T(0), T(0), T(0), T(0)};
+      if constexpr (!REAL) m = *reinterpret_cast<const V4 *>(in_im + o);
+      x[pc][0] = cx<T>{r.x, m.x}, x[pc][1] = cx<T>{r.y, m.y}, x[pc][2] = cx<T>{r.z, m.z}, x[pc][3] = cx<T>{r.w, m.w};
+    });
+    cx<T> y[4];
+    static_for<4>([&](auto j) {
+      if constexpr (P == 2) {
+        y[j] = h ? x[0][j] - x[1][j] : x[0][j] + x[1][j];
+      } else {
+        // output h of the 4-point DFT over the segments: sum_p x_p (-i)^(p h)
+        const cx<T> s02 = (h & 1) ? x[0][j] - x[2][j] : x[0][j] + x[2][j];
+        const cx<T> s13 = (h & 1) ? x[1][j] - x[3][j] : x[1][j] + x[3][j];
+        y[j] = h == 0 ? s02 + s13 : h == 2 ? s02 - s13 : h == 1 ? add_mul_neg_i(s02, s13) : add_mul_pos_i(s02, s13);
+      }
+    });
+    if (h) {  // wave-uniform
+      const cx<T> wq = look(h * 1024u * (unsigned)q);
+      static_for<4>([&](auto j) { y[j] = cmul(y[j], cmul(wt[j], wq)); });
+    }
+    a[q] = y[0], b[q] = y[1], c[q] = y[2], d[q] = y[3];
+  });
+
+  fft_passes<T, 12, false>(a, lds, twf, tid);  // a[e] = F0[tid + TP*e]
+  __syncthreads();                            // the buffer is reused by the next transform
+  fft_passes<T, 12, false>(b, lds, twf, tid);
+  __syncthreads();
+  fft_passes<T, 12, false>(c, lds, twf, tid);
+  __syncthreads();
+  fft_passes<T, 12, false>(d, lds, twf, tid);
+
+  // fft_split4_kernel's radix-4 combine; bin k of this sibling is X[P k + h]
+  T *const ore = out_re + base + h, *const oim = out_im + base + h;
+  auto put = [&](int k, cx<T> v) {
+    v = v * scale;
+    ore[(size_t)P * (size_t)(unsigned)k] = v.x;
+    oim[(size_t)P * (size_t)(unsigned)k] = v.y;
+  };
+  static_for<E>([&](auto ec) {
+    constexpr int e = ec;
+    const cx<T> t1 = cmul(b[e], mul_w64<T, e>(w1));
+    const cx<T> t2 = cmul(c[e], mul_w64<T, (2 * e) % 64>(w2));
+    const cx<T> t3 = cmul(d[e], mul_w64<T, (3 * e) % 64>(w3));
+    const cx<T> s0 = a[e] + t2, s1 = a[e] - t2, s2 = t1 + t3, d13 = t1 - t3;
+    put(0 * H + TP * e + tid, s0 + s2);
+    put(1 * H + TP * e + tid, add_mul_neg_i(s1, d13));
+    put(2 * H + TP * e + tid, s0 - s2);
+    put(3 * H + TP * e + tid, add_mul_pos_i(s1, d13));
+  });
+}
+
 // The same cut one size down, as a radix-2 step: N = 8192 rows as two 4096-point transforms of the
 // same 256 threads (x[2m], x[2m+1] arrive in one 2-wide load per plane) and
 //   X[k] = E[k] + W_8192^k O[k],   X[k + 4096] = E[k] - W_8192^k O[k]    in registers.

@@ -148,7 +148,9 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
     want = wre + 1j * wim
     rre_w, rim_w = oracle_mod.Plan(n).forward(re)
     res = {}
-    for mode in (1, 3, 0):   # 3: the scratch planes between the first two of three passes in natural order
+    # 1: default (2^15 / 2^16 out of place on fft_paired_kernel); 5: tile passes, current form; 3: their first form
+    # (natural-order scratch, 512-point factors on 16-wide tiles); 0: round 1's four-step forms
+    for mode in (1, 5, 3, 0):
         prev = pdsp.lib.pdsp_set_twopass(mode)
         try:
             dre, dim = torch.from_numpy(re).cuda(), torch.from_numpy(im).cuda()
@@ -168,8 +170,10 @@ def test_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_mod, log2n):
         finally:
             pdsp.lib.pdsp_set_twopass(prev)
         res[mode] = got
-    assert rel_err(res[1], res[0]) <= 2e-6
-    if log2n in (17, 18):                                 # 512-point factors: tile_rows512 / tile_cols512_kernel vs plain tiles
+    assert rel_err(res[1], res[0]) <= 2e-6 and rel_err(res[1], res[5]) <= 2e-6
+    if log2n in (15, 16):                                 # default = fft_paired_kernel: compare the two tile-pass forms
+        assert np.array_equal(res[5], res[3])
+    elif log2n in (17, 18):                                 # 512-point factors: tile_rows512 / tile_cols512_kernel vs plain tiles
         assert rel_err(res[1], res[3]) <= 2e-6
     else:
         assert np.array_equal(res[1], res[3])             # the same arithmetic, another scratch layout
