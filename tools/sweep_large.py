@@ -32,7 +32,7 @@ for log2n in (15, 16, 17, 18, 19, 20, 22, 24, 26):
     ore, oim = torch.empty_like(re), torch.empty_like(im)
     t = timed(lambda: plan.forward(re, im, out=(ore, oim)))
     c = 16.0 * batch * n / t / 1e9
-    line = f"{n:10d} {2 if log2n <= 18 else 3:7d} {c:10.0f} {c/8000:6.3f} {batch*n/t/1e9:10.1f}"
+    line = f"{n:10d} {1 if log2n <= 16 else 2 if log2n <= 18 else 3:7d} {c:10.0f} {c/8000:6.3f} {batch*n/t/1e9:10.1f}"
     if True:  # A/B: the tile passes' first form (3: natural-order scratch, 512-point rows on 16-row tiles); round 1's four-step forms (0)
         from pragma_dsp_amd import _capi
         for mode, label in ((5, "tile passes"), (3, "their first form"), (0, "round-1 four-step")):
