@@ -694,7 +694,7 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
         const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
 #define PDSP_PAIRED(LP, REAL)                                                                                        \
   hipLaunchKernelGGL((pdsp::fft_paired_kernel<T, LP, REAL>), dim3((unsigned)blocks), dim3(256), 0, s, re_in, im_in, re_out, \
-                     im_out, t.tw12, t.tws4, twa, twb, scale, batch)
+                     im_out, t.tw12, t.tws4, twa, twb, scale, batch, pdsp::PairedPacked{})
         if (lp == 1) {
           if (im_in) PDSP_PAIRED(1, false);
           else PDSP_PAIRED(1, true);
@@ -1299,6 +1299,25 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
           default: PDSP_SPLIT4_PACKED(3); break;
         }
 #undef PDSP_SPLIT4_PACKED
+        PDSP_HIP_TRY(hipGetLastError());
+      } else if (plan->log2n == 16 && g_twopass == 1 && t.tws4 && t.tw12) {
+        // N = 65536: the 32768-point transform in ONE pass by two sibling workgroups per frame that share an XCD's
+        // L2 (fft_paired_kernel, packed loader): 14 bytes per sample in all, where the two tile passes move 22
+        const long long blocks = ((batch + 7) / 8) * 8 * 2;
+        if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
+        const pdsp::PairedPacked pk{frame_stride, fw.wb, fw.we + 2 * 8, fw.we, fw.k0, fw.k1, fw.k2};
+        const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
+        const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
+#define PDSP_PAIRED_PACKED(PK)                                                                                       \
+  hipLaunchKernelGGL((pdsp::fft_paired_kernel<T, 1, false, PK>), dim3((unsigned)blocks), dim3(256), 0, stream, frames,   \
+                     first == 4 ? window : (const T *)nullptr, z_re, z_im, t.tw12, t.tws4, twa, twb, T(1), batch, pk)
+        switch (first) {
+          case 3: PDSP_PAIRED_PACKED(1); break;
+          case 4: PDSP_PAIRED_PACKED(2); break;
+          case 5: PDSP_PAIRED_PACKED(3); break;
+          default: PDSP_PAIRED_PACKED(4); break;
+        }
+#undef PDSP_PAIRED_PACKED
         PDSP_HIP_TRY(hipGetLastError());
       } else {
         if (int rc = tilepass_chain<T>(t, m, t.hp_np, t.hp_l, t.hp_tw, 1u, first, batch, frames, first == 4 ? window : nullptr,

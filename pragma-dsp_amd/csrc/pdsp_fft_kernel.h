@@ -1610,11 +1610,24 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
 // (If the dispatcher did not pair them the results would still be right: every workgroup is self-sufficient.)
 //   tw12 = radix table of the 4096-point transform; tws[k] = W_16384^k, k < 768 (fft_split4_kernel's);
 //   W_N^m = twa[m >> 9] * twb[m & 511]; REAL: Radix2Fft.forward rows (no imaginary plane).
-template <typename T, int LOG2P, bool REAL>
+// PK > 0: the rows are PACKED real frames (LoadPackedFrames' layout: point m = (x[2m], x[2m+1]) of a frame of 2N
+// samples, `pk.stride` samples apart) -- the one transform pass of spectrum() on frames of 2 * P * 16384 samples,
+// split_amp_rows_kernel undoes the packing -- times the window: PK - 1 = 0 rect, 1 window table (in_im), 2 / 3
+// two- / three-term cosine-sum window evaluated in registers (LoadPackedFrames' tables; segment p adds the angle
+// 32768 f p = 2 * (8 * 2048 f)).  twa / twb then belong to the plan of 2N points: W_N^m = W_2N^(2m).
+struct PairedPacked {
+  long long stride;
+  const float *wb, *wq, *we;
+  float k0, k1, k2;
+};
+template <typename T, int LOG2P, bool REAL, int PK = 0>
 __global__ void __launch_bounds__(256, 2)
 fft_paired_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *__restrict__ out_re, T *__restrict__ out_im,
                   const typename vec2<T>::type *__restrict__ tw12, const typename vec2<T>::type *__restrict__ tws,
-                  const cx<T> *__restrict__ twa, const cx<T> *__restrict__ twb, const T scale, const long long batch) {
+                  const cx<T> *__restrict__ twa, const cx<T> *__restrict__ twb, const T scale, const long long batch,
+                  const PairedPacked pk) {
+  static_assert(PK == 0 || (!REAL && sizeof(T) == 4 && LOG2P == 1), "packed frames: f32, two siblings");
+  constexpr unsigned TSH = PK ? 1u : 0u;
   using TR = FftTraits<12>;
   constexpr int E = 16, TP = 256, H = 4096, S = 4 * H, P = 1 << LOG2P, N = P * S;
   static_assert(LOG2P == 1 || LOG2P == 2, "two or four siblings");
@@ -1632,9 +1645,15 @@ fft_paired_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *_
   const cx<T> *const twn = reinterpret_cast<const cx<T> *>(tws);
   const cx<T> w1 = twn[(unsigned)tid], w2 = twn[(unsigned)(2 * tid)], w3 = twn[(unsigned)(3 * tid)];
   // W_N^(h n), n = 4 (tid + 256 q) + j:  wt[j] = W_N^(h (4 tid + j)) per thread, wq = W_N^(1024 h q) per q (wave-uniform)
-  auto look = [&](unsigned m) { return cmul(twa[m >> 9], twb[m & 511]); };
+  auto look = [&](unsigned m) { return cmul(twa[(m << TSH) >> 9], twb[(m << TSH) & 511]); };
   cx<T> wt[4];
   static_for<4>([&](auto j) { wt[j] = look(h * (unsigned)(4 * tid + j)); });
+  cx<T> wcs{T(1), T(0)}, wseg{T(1), T(0)};  // PK >= 3: cs(8 f tid); cs(32768 f) = cs(8 * 2048 f)^2
+  if constexpr (PK >= 3) {
+    wcs = reinterpret_cast<const cx<T> *>(pk.wb)[(unsigned)tid];
+    const cx<T> w8 = reinterpret_cast<const cx<T> *>(pk.wq)[8];
+    wseg = cmul(w8, w8);
+  }
   load_order_fence();
 
   const size_t base = (size_t)t * (size_t)N;
@@ -1643,12 +1662,32 @@ fft_paired_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *_
     constexpr int q = qc;
     cx<T> x[P][4];
     static_for<P>([&](auto pc) {
-      const size_t o = base + (size_t)pc * S + 4 * (size_t)(TP * q + tid);
       // plain (not non-temporal) accesses on both sides: the siblings' reuse lives in the XCD's L2
-      const V4 r = *reinterpret_cast<const V4 *>(in_re + o);
-      V4 m = V4{T(0), T(0), T(0), T(0)};
-      if constexpr (!REAL) m = *reinterpret_cast<const V4 *>(in_im + o);
-      x[pc][0] = cx<T>{r.x, m.x}, x[pc][1] = cx<T>{r.y, m.y}, x[pc][2] = cx<T>{r.z, m.z}, x[pc][3] = cx<T>{r.w, m.w};
+      if constexpr (PK > 0) {
+        // points 4m .. 4m+3 of segment p = samples 8m .. 8m+7 of the frame's half p: two 16-byte loads
+        const size_t so = (size_t)t * (size_t)pk.stride + (size_t)pc * (2 * S) + 8 * (size_t)(TP * q + tid);
+        V4 r0 = *reinterpret_cast<const V4 *>(in_re + so), r1 = *(reinterpret_cast<const V4 *>(in_re + so) + 1);
+        if constexpr (PK == 2) {
+          const size_t wo = (size_t)pc * (2 * S) + 8 * (size_t)(TP * q + tid);
+          r0 = r0 * *reinterpret_cast<const V4 *>(in_im + wo);
+          r1 = r1 * *(reinterpret_cast<const V4 *>(in_im + wo) + 1);
+        }
+        if constexpr (PK >= 3) {
+          cx<T> c0 = cmul(wcs, reinterpret_cast<const cx<T> *>(pk.wq)[q]);  // wave-uniform: scalar loads
+          if constexpr (pc == 1) c0 = cmul(c0, wseg);
+          cx<T> w[4];
+          fused_window_pairs<T, PK == 4>(c0, reinterpret_cast<const cx<T> *>(pk.we), pk.k0, pk.k1, pk.k2, w);
+          r0 = r0 * V4{w[0].x, w[0].y, w[1].x, w[1].y};
+          r1 = r1 * V4{w[2].x, w[2].y, w[3].x, w[3].y};
+        }
+        x[pc][0] = cx<T>{r0.x, r0.y}, x[pc][1] = cx<T>{r0.z, r0.w}, x[pc][2] = cx<T>{r1.x, r1.y}, x[pc][3] = cx<T>{r1.z, r1.w};
+      } else {
+        const size_t o = base + (size_t)pc * S + 4 * (size_t)(TP * q + tid);
+        const V4 r = *reinterpret_cast<const V4 *>(in_re + o);
+        V4 m = V4{T(0), T(0), T(0), T(0)};
+        if constexpr (!REAL) m = *reinterpret_cast<const V4 *>(in_im + o);
+        x[pc][0] = cx<T>{r.x, m.x}, x[pc][1] = cx<T>{r.y, m.y}, x[pc][2] = cx<T>{r.z, m.z}, x[pc][3] = cx<T>{r.w, m.w};
+      }
     });
     cx<T> y[4];
     static_for<4>([&](auto j) {
