@@ -146,7 +146,7 @@ struct Tables {
   T2 *twa = nullptr;
   T2 *twb = nullptr;
   T2 *tw1 = nullptr;  // general four-step path (log2n1 > kMaxLog2N1): radix table of the N1-point rows
-  // tile passes (f32): N = product of tp_np balanced factors 2^tp_l[i] (two for 2^15..2^17, three for
+  // tile passes (f32): N = product of tp_np balanced factors 2^tp_l[i] (two for 2^15..2^18, three for
   // 2^18..2^27), radix table of each factor's transform
   int tp_np = 0;
   int tp_l[3] = {0, 0, 0};
@@ -707,7 +707,7 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
         return PDSP_OK;
       }
     }
-    // tile passes with balanced factors (two for 2^15..2^17, three for 2^19..2^27) where the tables exist and
+    // tile passes with balanced factors (two for 2^15..2^18, three for 2^19..2^27) where the tables exist and
     // every plane is 16-byte aligned; pdsp_set_twopass(0) keeps round 1's four-step forms (A/B tests)
     if (t.tp_np && (g_twopass & 1) &&
         (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {

@@ -2049,7 +2049,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   }
 }
 
-// ---- tile passes: two passes for 2^15 <= N <= 2^17, three for 2^19 <= N <= 2^27 (f32) -----------
+// ---- tile passes: two passes for 2^15 <= N <= 2^18, three for 2^19 <= N <= 2^27 (f32) -----------
 // N is cut into BALANCED factors of 64 ... 512 points instead of N1 * 16384, and every pass is one launch
 // of tile_pass_kernel: a 256-thread workgroup owns TILE transforms of one factor, moves them between HBM
 // and LDS in 128 ... 256-byte segments, runs them in LDS (fft_passes on the tile's LDS rows, 256/TP rows
