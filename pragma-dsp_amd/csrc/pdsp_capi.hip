@@ -147,7 +147,7 @@ struct Tables {
   T2 *twb = nullptr;
   T2 *tw1 = nullptr;  // general four-step path (log2n1 > kMaxLog2N1): radix table of the N1-point rows
   // tile passes (f32): N = product of tp_np balanced factors 2^tp_l[i] (two for 2^15..2^18, three for
-  // 2^18..2^27), radix table of each factor's transform
+  // 2^19..2^27), radix table of each factor's transform
   int tp_np = 0;
   int tp_l[3] = {0, 0, 0};
   T2 *tp_tw[3] = {nullptr, nullptr, nullptr};
