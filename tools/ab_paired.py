@@ -14,18 +14,23 @@ for log2n in (15, 16):
     plan = BatchedFft(n, dev)
     re, im = torch.randn((batch, n), device=dev), torch.randn((batch, n), device=dev)
     ore, oim = torch.empty_like(re), torch.empty_like(im)
-    for rep in range(2):
-        for mode in (1, 5):
-            prev = _capi.lib.pdsp_set_twopass(mode)
-            for _ in range(5):
-                plan.forward(re, im, out=(ore, oim))
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                plan.forward(re, im, out=(ore, oim))
-            e1.record()
-            torch.cuda.synchronize()
-            _capi.lib.pdsp_set_twopass(prev)
-            t = e0.elapsed_time(e1) / 20 * 1e-3
-            print(f"N=2^{log2n} {'paired, one pass' if mode == 1 else 'two tile passes '}: {16.0 * batch * n / t / 1e9:6.0f} GB/s algorithmic", flush=True)
+    calls = (("forwardComplex", 16.0, lambda: plan.forward(re, im, out=(ore, oim))),
+             ("forward (real) ", 12.0, lambda: plan.forward(re, out=(ore, oim))),
+             ("inverse        ", 16.0, lambda: plan.inverse(re, im, out=(ore, oim))))
+    for name, nbytes, fn in calls:
+        for rep in range(2 if name.startswith("forwardC") else 1):
+            for mode in (1, 5):
+                prev = _capi.lib.pdsp_set_twopass(mode)
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                _capi.lib.pdsp_set_twopass(prev)
+                t = e0.elapsed_time(e1) / 20 * 1e-3
+                print(f"N=2^{log2n} {name} {'paired, one pass' if mode == 1 else 'two tile passes '}: "
+                      f"{nbytes * batch * n / t / 1e9:6.0f} GB/s algorithmic", flush=True)
