@@ -1658,15 +1658,38 @@ fft_paired_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *_
 
   const size_t base = (size_t)t * (size_t)N;
   cx<T> a[E], b[E], c[E], d[E];
-  static_for<E>([&](auto qc) {
-    constexpr int q = qc;
-    cx<T> x[P][4];
+  // The loads run AHEAD of the arithmetic by DEPTH steps of q, in slots of their own: left to itself hipcc waits
+  // for each step's loads (vmcnt(0)) before it issues the next step's -- sixteen exposed round trips per workgroup,
+  // on a kernel that is bound by one workgroup's critical path, not by HBM.
+  constexpr int DEPTH = P == 2 ? 3 : 1, SLOTS = DEPTH + 1;
+  V4 l0[SLOTS][P], l1[SLOTS][P];  // planar: re / im of four points; packed: samples 8m .. 8m+3 / 8m+4 .. 8m+7
+  auto issue = [&](auto qc, auto sc) {
+    constexpr int q = qc, sl = sc;
     static_for<P>([&](auto pc) {
       // plain (not non-temporal) accesses on both sides: the siblings' reuse lives in the XCD's L2
       if constexpr (PK > 0) {
         // points 4m .. 4m+3 of segment p = samples 8m .. 8m+7 of the frame's half p: two 16-byte loads
         const size_t so = (size_t)t * (size_t)pk.stride + (size_t)pc * (2 * S) + 8 * (size_t)(TP * q + tid);
-        V4 r0 = *reinterpret_cast<const V4 *>(in_re + so), r1 = *(reinterpret_cast<const V4 *>(in_re + so) + 1);
+        l0[sl][pc] = *reinterpret_cast<const V4 *>(in_re + so);
+        l1[sl][pc] = *(reinterpret_cast<const V4 *>(in_re + so) + 1);
+      } else {
+        const size_t o = base + (size_t)pc * S + 4 * (size_t)(TP * q + tid);
+        l0[sl][pc] = *reinterpret_cast<const V4 *>(in_re + o);
+        if constexpr (!REAL) l1[sl][pc] = *reinterpret_cast<const V4 *>(in_im + o);
+      }
+    });
+  };
+  static_for<DEPTH>([&](auto qc) { issue(qc, std::integral_constant<int, qc % SLOTS>{}); });
+  static_for<E>([&](auto qc) {
+    constexpr int q = qc, sl = q % SLOTS;
+    if constexpr (q + DEPTH < E) {
+      issue(std::integral_constant<int, q + DEPTH>{}, std::integral_constant<int, (q + DEPTH) % SLOTS>{});
+      load_order_fence();
+    }
+    cx<T> x[P][4];
+    static_for<P>([&](auto pc) {
+      if constexpr (PK > 0) {
+        V4 r0 = l0[sl][pc], r1 = l1[sl][pc];
         if constexpr (PK == 2) {
           const size_t wo = (size_t)pc * (2 * S) + 8 * (size_t)(TP * q + tid);
           r0 = r0 * *reinterpret_cast<const V4 *>(in_im + wo);
@@ -1682,10 +1705,9 @@ fft_paired_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *_
         }
         x[pc][0] = cx<T>{r0.x, r0.y}, x[pc][1] = cx<T>{r0.z, r0.w}, x[pc][2] = cx<T>{r1.x, r1.y}, x[pc][3] = cx<T>{r1.z, r1.w};
       } else {
-        const size_t o = base + (size_t)pc * S + 4 * (size_t)(TP * q + tid);
-        const V4 r = *reinterpret_cast<const V4 *>(in_re + o);
+        const V4 r = l0[sl][pc];
         V4 m = V4{T(0), T(0), T(0), T(0)};
-        if constexpr (!REAL) m = *reinterpret_cast<const V4 *>(in_im + o);
+        if constexpr (!REAL) m = l1[sl][pc];
         x[pc][0] = cx<T>{r.x, m.x}, x[pc][1] = cx<T>{r.y, m.y}, x[pc][2] = cx<T>{r.z, m.z}, x[pc][3] = cx<T>{r.w, m.w};
       }
     });
