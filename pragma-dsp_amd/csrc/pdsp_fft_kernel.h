@@ -1661,7 +1661,13 @@ fft_paired_kernel(const T *__restrict__ in_re, const T *__restrict__ in_im, T *_
   // The loads run AHEAD of the arithmetic by DEPTH steps of q, in slots of their own: left to itself hipcc waits
   // for each step's loads (vmcnt(0)) before it issues the next step's -- sixteen exposed round trips per workgroup,
   // on a kernel that is bound by one workgroup's critical path, not by HBM.
-  constexpr int DEPTH = P == 2 ? 3 : 1, SLOTS = DEPTH + 1;
+#ifndef PDSP_PAIRED_DEPTH2
+#define PDSP_PAIRED_DEPTH2 5  /* steps of q in flight, two siblings (3: -6 %, 7: no better; tools/ab_paired.py) */
+#endif
+#ifndef PDSP_PAIRED_DEPTH4
+#define PDSP_PAIRED_DEPTH4 2  /* four siblings, twice the registers per step (1: -4 %; 3 spills) */
+#endif
+  constexpr int DEPTH = P == 2 ? PDSP_PAIRED_DEPTH2 : PDSP_PAIRED_DEPTH4, SLOTS = DEPTH + 1;
   V4 l0[SLOTS][P], l1[SLOTS][P];  // planar: re / im of four points; packed: samples 8m .. 8m+3 / 8m+4 .. 8m+7
   auto issue = [&](auto qc, auto sc) {
     constexpr int q = qc, sl = sc;
