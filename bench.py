@@ -345,6 +345,44 @@ def read_clocks(dev=None, ours_only=False):
     return out or None
 
 
+EXIT_PARITY_FAILED = 4       # the in-run oracle check of the timed output failed: the line is not a measurement
+EXIT_EXCHANGE_ABANDONED = 5  # the exchange leg (RCCL all-gather) did not return in time: value measured, hang reported
+
+
+class ExchangeWatchdog:
+    """Guards the one step of the path that can hang on a sick collective library: the final gather.  If `done()`
+    has not been called `timeout` seconds after `start()`, rank 0's line -- which already carries the measured value
+    -- is printed with `gather.error`, and EVERY rank leaves with EXIT_EXCHANGE_ABANDONED (os._exit: the main thread
+    is inside a collective that will not return).  A process that gave up on a stuck GPU collective must not
+    report success: the launcher (and torch.distributed.run) see the status, the line is still on stdout."""
+
+    def __init__(self, timeout: float, rank: int, out, gather: dict):
+        self.timeout, self.rank, self.out, self.gather = timeout, rank, out, gather
+        self.lock = threading.Lock()
+        self._done = threading.Event()
+
+    def start(self):
+        threading.Thread(target=self._watch, daemon=True).start()
+        return self
+
+    def done(self):
+        self._done.set()
+
+    def _watch(self):
+        if self._done.wait(self.timeout):
+            return
+        with self.lock:  # the main thread is inside a collective, not inside an update of `gather`
+            self.gather["error"] = (f"exchange still running after {self.timeout:g} s: abandoned (exit status "
+                                    f"{EXIT_EXCHANGE_ABANDONED}), the measured value stands")
+            if self.rank == 0:
+                self.out["gather"] = self.gather
+                print(json.dumps(self.out), flush=True)
+                sys.stdout.flush()
+        if self.rank != 0:
+            time.sleep(1.0)  # rank 0 prints first
+        os._exit(EXIT_PARITY_FAILED if (self.rank == 0 and parity_failures(self.out)) else EXIT_EXCHANGE_ABANDONED)
+
+
 def launch_ranks(args, argv) -> int:
     """`--gpus N` without WORLD_SIZE in the environment: start N child ranks of this script, one per
     GPU (LOCAL_RANK = rank), wait for them, relay rank 0's JSON line.  This parent never calls into
@@ -352,6 +390,7 @@ def launch_ranks(args, argv) -> int:
     the others stop and the parent exit non-zero."""
     import socket
     import subprocess
+    import tempfile
     n = args.gpus
     if not args.dry_run and not args.share_gpu:
         have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
@@ -363,14 +402,17 @@ def launch_ranks(args, argv) -> int:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    # rank 0's stdout goes to a file, not a pipe: a pipe nobody reads while the child runs blocks the child once
+    # 64 KiB are in it (stray prints of torch / RCCL, a long line), and the launch would end as a timeout
+    out0_file = tempfile.TemporaryFile(mode="w+", prefix="pdsp_bench_rank0_")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PDSP_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=out0_file if r == 0 else subprocess.DEVNULL, text=True))
     deadline = time.time() + args.launch_timeout
-    rc, out0 = 0, None
+    rc = 0
     pending = set(range(n))
     while pending:
         for r in sorted(pending):
@@ -378,31 +420,40 @@ def launch_ranks(args, argv) -> int:
             if code is None:
                 continue
             pending.discard(r)
-            if r == 0:
-                out0 = procs[0].stdout.read()
             if code != 0:
-                rc = rc or code or 1
+                # the first failure decides the status, except that a rank killed by a signal never outranks a
+                # rank that chose its own status (EXIT_EXCHANGE_ABANDONED from every rank, say)
+                rc = code if (rc == 0 or (rc < 0 < code)) else rc
                 print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
         if (rc or time.time() > deadline) and pending:
             if not rc:
                 print(f"bench.py: ranks {sorted(pending)} still running after {args.launch_timeout} s", file=sys.stderr)
                 rc = 124
-            for r in pending:  # exactly the children started above
-                procs[r].kill()
-            for r in pending:
-                procs[r].wait()
-            if 0 in pending:
-                out0 = procs[0].stdout.read()
+            else:
+                # ranks that end on their own within a moment (every rank of an abandoned exchange does) keep
+                # their own status; only the rest are stopped
+                t_grace = time.time() + 10.0
+                while time.time() < t_grace and any(procs[r].poll() is None for r in pending):
+                    time.sleep(0.05)
+            for r in sorted(pending):  # exactly the children started above
+                if procs[r].poll() is None:
+                    procs[r].kill()
+            for r in sorted(pending):
+                code = procs[r].wait()
+                if code not in (0, -9):
+                    print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
             pending.clear()
         elif pending:
             time.sleep(0.05)
-    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    out0_file.seek(0)
+    lines = [ln for ln in out0_file.read().splitlines() if ln.startswith("{")]
+    out0_file.close()
     if rc == 0 and not lines:
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
         rc = 1
-    if rc == 0:
+    if lines:  # a measurement that was printed survives a later failure (the status still says what happened)
         print(lines[-1], flush=True)
-    return rc
+    return rc if rc >= 0 else 128 - rc
 
 
 def parse_args(argv):
@@ -415,7 +466,9 @@ def parse_args(argv):
     ap.add_argument("--n", type=int, default=None, help="spectrum256 only: another frame size (development sweeps)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle baseline + parity rows)")
-    ap.add_argument("--no-also", action="store_true", help="skip the short configs[3] leg attached to the default line")
+    ap.add_argument("--no-also", action="store_true", help="skip the configs[3] and f64 legs attached to the default line")
+    ap.add_argument("--also-reuse-chunk", action="store_true",
+                    help="the configs[3] leg re-reads one 1-GiB chunk instead of keeping the whole 96-GiB stream resident")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ramp-seconds", type=float, default=0.6, help="untimed clock-ramp before the warm-up steps")
     ap.add_argument("--dist-backend", default=None,
@@ -435,6 +488,15 @@ def parse_args(argv):
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no compute: launcher + rendezvous + shard + gather + max-over-ranks only (CPU tests)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="testing the launcher: this rank exits with status 3")
+    ap.add_argument("--stdout-noise", type=int, default=0,
+                    help="testing the launcher: rank 0 first writes this many bytes of non-JSON text to its stdout")
+    ap.add_argument("--simulate-hang", action="store_true",
+                    help="--dry-run only: the gather of rank 1 (rank 0 in a world of one) never returns, so that the "
+                         "watchdog's path -- line printed, every rank exits 5 -- is testable without a GPU")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N = 1: after a short timed run, the exchange leg in a world of ONE rank -- an RCCL group made the "
+                         "same way (`new_group(backend='nccl', device_id=...)`), all_gather_into_tensor on the real output "
+                         "planes and on the 16-byte peak records, an orderly destroy: what one card can prove about the leg")
     ap.add_argument("--launch-timeout", type=float, default=900.0)
     args = ap.parse_args(argv)
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -459,15 +521,21 @@ def dry_run(args, world: int, rank: int) -> int:
         dist.barrier()
     t0 = time.perf_counter()
     rec = torch.arange(row0, row1, dtype=torch.int32).reshape(-1, 1).repeat(1, 4)  # 16 B per row
+    line = {"metric": "dry-run (launcher / shard / gather plumbing only, no compute)", "value": None,
+            "unit": "GSample/s", "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
+            "rows": [row0, row1], "global_batch": per_gpu * world, "backend": args.dist_backend}
+    gather = {"backend": args.dist_backend}
+    dog = ExchangeWatchdog(args.gather_timeout, rank, line, gather).start()  # the real leg's guard, same statuses
+    if args.simulate_hang and rank == min(1, world - 1):
+        threading.Event().wait()  # this rank never reaches the collective: every other rank hangs inside it
     full = gather_rows(rec, per_gpu * world)
+    dog.done()
     ok = bool(torch.equal(full[:, 0], torch.arange(per_gpu * world, dtype=torch.int32)))
     elapsed = max_over_ranks(time.perf_counter() - t0)
     ranks_seen = max_over_ranks(float(rank + 1))
     if rank == 0:
-        print(json.dumps({"metric": "dry-run (launcher / shard / gather plumbing only, no compute)", "value": None,
-                          "unit": "GSample/s", "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
-                          "rows": [row0, row1], "global_batch": per_gpu * world, "gather_ok": ok,
-                          "ranks_seen": int(ranks_seen), "elapsed_s": elapsed, "backend": args.dist_backend}), flush=True)
+        line.update({"gather_ok": ok, "ranks_seen": int(ranks_seen), "elapsed_s": elapsed})
+        print(json.dumps(line), flush=True)
     return 0 if ok else 1
 
 
@@ -485,7 +553,15 @@ def main(argv=None) -> int:
     if rank == args.fail_rank:
         print(f"bench.py: rank {rank} failing on request (--fail-rank)", file=sys.stderr)
         return 3
-    if world > 1:
+    if args.stdout_noise and rank == 0:
+        for _ in range(0, args.stdout_noise, 64):
+            print("stray line from a library, not the result" + " " * 22, flush=True)
+    if args.rccl_selftest and world == 1:  # a process group of one: the exchange leg needs a control plane
+        with __import__("socket").socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+    if world > 1 or args.rccl_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist
         # Control plane (barriers, max-over-ranks, per-rank read-outs: a few host scalars) over gloo on loopback --
@@ -499,7 +575,7 @@ def main(argv=None) -> int:
             return dry_run(args, world, rank)
         return run_rank(args, world, rank, local)
     finally:
-        if world > 1:
+        if world > 1 or args.rccl_selftest:
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.destroy_process_group()
@@ -749,7 +825,8 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                 out["parity"] = parity_vs_oracle("spectrum", (re[sel].cpu().numpy(),),
                                                  (amp[sel].cpu().numpy().astype(np.float64),), n, "hann")
         if world == 1 and args.workload == "fft4096" and not args.no_also:
-            out["also"] = {"spectrum16k": also_spectrum16k(args, dev, rank)}
+            out["also"] = {"spectrum16k": also_spectrum16k(args, dev, rank),
+                           "fft4096_f64": also_fft4096_f64(args, dev, rank, re, im)}
         if world == 1 and not args.no_cpu_baseline:
             rows = 2048
             sel = torch.cat([torch.arange(0, rows // 2), torch.arange(per_gpu // 2, per_gpu // 2 + rows // 2)]) \
@@ -758,82 +835,10 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
             him = im[sel.to(dev)].cpu().numpy().astype(np.float64) if im is not None else None
             out["cpu_baseline"] = cpu_baseline(hre, him, n, args.cpu_seconds)
     # The one exchange step of the path, timed on its own AFTER the line is assembled: the value is
-    # already measured, so neither a failed nor a hung exchange may take it away.  A watchdog thread prints rank 0's
-    # line with `gather.error` and ends every rank with status 0 if the exchange has not returned in time.
+    # already measured, so neither a failed nor a hung exchange may take it away (exchange_leg below).
     gather = None
-    if world > 1 and not args.no_gather and args.workload in ("fft4096", "real4096"):
-        gather = {"backend": args.dist_backend}
-        exchange_done, lock = threading.Event(), threading.Lock()
-
-        def watchdog():
-            if exchange_done.wait(args.gather_timeout):
-                return
-            with lock:  # the main thread is inside a collective, not inside an update of `gather`
-                gather["error"] = f"exchange still running after {args.gather_timeout:g} s: abandoned, the measured value stands"
-                if rank == 0:
-                    out["gather"] = gather
-                    print(json.dumps(out), flush=True)
-            if rank != 0:
-                time.sleep(2.0)  # rank 0 prints first
-            os._exit(4 if (rank == 0 and parity_failures(out)) else 0)
-        threading.Thread(target=watchdog, daemon=True).start()
-
-        # (i) the full output slabs: at 2 GiB/rank the all-gather is xGMI-per-link bound and dwarfs the compute.
-        # (ii) the reduced output a consumer of spectrum() needs -- one 16-byte SpectrumPeak per frame (fused
-        # findPeak over the rows' real plane): ~1 MiB/rank.
-        xgrp = [None]  # the exchange group: RCCL (created below, inside the guarded leg), or the gloo default group
-
-        def timed_gather(tensors, rows_per_rank):
-            gather_rows(tensors[0][:8], 8 * world, xgrp[0])  # communicator warm-up, untimed
-            barrier()
-            g0 = time.perf_counter()
-            outs = [gather_rows(t, rows_per_rank * world, xgrp[0]) for t in tensors]
-            torch.cuda.synchronize(dev)
-            sec = max_over_ranks(time.perf_counter() - g0)
-            nbytes = sum(t.numel() * t.element_size() for t in tensors)
-            rows = int(outs[0].shape[0])
-            del outs
-            return {"ms": sec * 1e3, "bytes_per_rank": nbytes, "GBps_in_per_gpu": nbytes * (world - 1) / sec / 1e9,
-                    "rows_gathered": rows}
-        try:  # a failed exchange is reported, not fatal
-            pk_i, pk_f, pk_a, pk_p, _, _ = plan.spectrum_peaks(re, "hann", "one", 48000.0)
-            recs = pk_i.new_empty((per_gpu, 4))
-            recs[:, 0] = pk_i
-            recs[:, 1:] = torch.stack([pk_f, pk_a, pk_p], dim=1).view(torch.int32)
-            torch.cuda.synchronize(dev)
-            if args.dist_backend != "nccl":
-                # gloo rehearsal (1-GPU box): the collective runs on host copies, 4096 rows of the slabs per
-                # rank -- it checks the plumbing; it is not a bandwidth figure
-                legs = (("slabs", lambda: timed_gather([ore[:4096].cpu(), oim[:4096].cpu()], 4096)),
-                        ("peaks_16B_per_frame", lambda: timed_gather([recs.cpu()], per_gpu)))
-                with lock:
-                    gather["note"] = "gloo rehearsal on host copies (slabs: 4096 rows per rank)"
-            else:
-                # RCCL comes up here, as a group of its own (one communicator per rank, bound to its card); the
-                # ranks then agree over the control plane that it did, so that a failed bring-up is skipped by
-                # all of them together instead of leaving some inside a collective
-                import torch.distributed as dist
-                up, why = 1.0, ""
-                try:
-                    xgrp[0] = dist.new_group(backend="nccl", device_id=dev)
-                    gather_rows(recs[:8], 8 * world, xgrp[0])
-                    torch.cuda.synchronize(dev)
-                except Exception as exc:  # noqa: BLE001
-                    up, why = 0.0, f"{type(exc).__name__}: {exc}"
-                if max_over_ranks(1.0 - up) > 0.0:
-                    raise RuntimeError("RCCL group did not come up on every rank" + (f" (this rank: {why})" if why else ""))
-                # the small exchange first: it is the one a consumer of spectrum() needs
-                legs = (("peaks_16B_per_frame", lambda: timed_gather([recs], per_gpu)),
-                        ("slabs", lambda: timed_gather([ore, oim], per_gpu)))
-            for name, leg in legs:
-                res = leg()
-                with lock:
-                    gather[name] = res
-        except Exception as exc:  # noqa: BLE001  (RuntimeError from RCCL / allocator)
-            with lock:
-                gather["error"] = f"{type(exc).__name__}: {exc}"[:300]
-        finally:
-            exchange_done.set()
+    if (world > 1 or args.rccl_selftest) and not args.no_gather and args.workload in ("fft4096", "real4096"):
+        gather = exchange_leg(args, world, rank, dev, plan, re, ore, oim, per_gpu, out, barrier)
 
     if rank == 0:
         if gather:
@@ -843,56 +848,253 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         if bad:  # a fast kernel whose results differ from the reference's is not done: say so loudly
             print(f"bench.py: PARITY FAILED against the oracle ({', '.join(bad)}): the line above is not a valid measurement",
                   file=sys.stderr)
-            return 4
+            return EXIT_PARITY_FAILED
     return 0
+
+
+def exchange_leg(args, world: int, rank: int, dev, plan, re, ore, oim, per_gpu: int, out, barrier) -> dict:
+    """The path's one exchange step (north_star: "RCCL over xGMI only for the final gather"), after the
+    timed region: the all-gather of (i) one 16-byte SpectrumPeak record per frame (fused findPeak over the rows'
+    real plane: ~1 MiB per rank -- what a consumer of spectrum() needs) and (ii) the full output slabs (2 GiB per
+    rank at configs[4]: xGMI-per-link bound, it dwarfs the compute), each timed on its own.  RCCL comes up HERE, as a
+    process group of its own (one communicator per rank, bound to its card), the ranks agree over the gloo control
+    plane that it did -- a failed bring-up is skipped by all of them together -- and the group is destroyed before
+    the leg returns, on every path.  A failed exchange is `gather.error` in the line; a hung one is abandoned by the
+    watchdog with a non-zero status.  `--rccl-selftest` runs the same leg in a world of ONE rank (the collective
+    is not short-cut), which is what a 1-GPU box can prove: librccl loads, the eager `device_id` bring-up works,
+    all_gather_into_tensor runs on the real planes, teardown is clean."""
+    import torch.distributed as dist
+    from pragma_dsp_amd.shard import gather_rows, max_over_ranks
+    gather = {"backend": args.dist_backend}
+    dog = ExchangeWatchdog(args.gather_timeout, rank, out, gather).start()
+    xgrp = None  # the exchange group: RCCL (created below, inside the guarded leg), or the gloo default group
+
+    def timed_gather(tensors, rows_per_rank, check=False):
+        gather_rows(tensors[0][:8], 8 * world, xgrp, force_collective=True)  # communicator warm-up, untimed
+        barrier()
+        g0 = time.perf_counter()
+        outs = [gather_rows(t, rows_per_rank * world, xgrp, force_collective=True) for t in tensors]
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+        sec = max_over_ranks(time.perf_counter() - g0)
+        nbytes = sum(t.numel() * t.element_size() for t in tensors)
+        res = {"ms": sec * 1e3, "bytes_per_rank": nbytes, "GBps_in_per_gpu": nbytes * (world - 1) / sec / 1e9,
+               "rows_gathered": int(outs[0].shape[0])}
+        if check:  # this rank's own rows came back where they belong, bit for bit
+            r0 = rank * rows_per_rank
+            res["own_rows_intact"] = bool(all(torch.equal(o[r0:r0 + rows_per_rank], t) for o, t in zip(outs, tensors)))
+        del outs
+        return res
+    try:  # a failed exchange is reported, not fatal
+        pk_i, pk_f, pk_a, pk_p, _, _ = plan.spectrum_peaks(re, "hann", "one", 48000.0)
+        recs = pk_i.new_empty((per_gpu, 4))
+        recs[:, 0] = pk_i
+        recs[:, 1:] = torch.stack([pk_f, pk_a, pk_p], dim=1).view(torch.int32)
+        torch.cuda.synchronize(dev)
+        if args.dist_backend != "nccl":
+            # gloo rehearsal (1-GPU box): the collective runs on host copies, 4096 rows of the slabs per
+            # rank -- it checks the plumbing; it is not a bandwidth figure
+            legs = (("slabs", lambda: timed_gather([ore[:4096].cpu(), oim[:4096].cpu()], 4096)),
+                    ("peaks_16B_per_frame", lambda: timed_gather([recs.cpu()], per_gpu)))
+            with dog.lock:
+                gather["note"] = "gloo rehearsal on host copies (slabs: 4096 rows per rank)"
+                gather["ranks"] = dist.get_world_size()
+        else:
+            up, why = 1.0, ""
+            try:
+                xgrp = dist.new_group(backend="nccl", device_id=dev)
+                gather_rows(recs[:8], 8 * world, xgrp, force_collective=True)
+                torch.cuda.synchronize(dev)
+            except Exception as exc:  # noqa: BLE001
+                up, why = 0.0, f"{type(exc).__name__}: {exc}"
+            if max_over_ranks(1.0 - up) > 0.0:
+                raise RuntimeError("RCCL group did not come up on every rank" + (f" (this rank: {why})" if why else ""))
+            with dog.lock:
+                gather["ranks"] = dist.get_world_size(xgrp)  # the ranks RCCL itself saw
+                try:
+                    gather["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:  # noqa: BLE001
+                    gather["rccl_version"] = None
+            # the small exchange first: it is the one a consumer of spectrum() needs, and one line survives a
+            # failure of the slab exchange
+            legs = (("peaks_16B_per_frame", lambda: timed_gather([recs], per_gpu, check=True)),
+                    ("slabs", lambda: timed_gather([ore, oim], per_gpu, check=True)))
+        for name, leg in legs:
+            res = leg()
+            with dog.lock:
+                gather[name] = res
+    except Exception as exc:  # noqa: BLE001  (RuntimeError from RCCL / allocator)
+        with dog.lock:
+            gather["error"] = f"{type(exc).__name__}: {exc}"[:300]
+    finally:
+        try:  # still under the watchdog: a teardown that hangs is a hang
+            if xgrp is not None:
+                torch.cuda.synchronize(dev)
+                dist.destroy_process_group(xgrp)
+                with dog.lock:
+                    gather["group_destroyed"] = True
+        except Exception as exc:  # noqa: BLE001
+            with dog.lock:
+                gather["destroy_error"] = f"{type(exc).__name__}: {exc}"[:200]
+        dog.done()
+    return gather
 
 
 def parity_failures(out) -> list:
     """Names of the in-run oracle checks of a bench line that failed (empty = the line is a valid measurement)."""
     bad = [k for k in ("parity",) if k in out and not out[k]["ok"]]
-    if "also" in out and "parity" in out["also"]["spectrum16k"] and not out["also"]["spectrum16k"]["parity"]["ok"]:
-        bad.append("also.spectrum16k.parity")
+    for leg, res in (out.get("also") or {}).items():
+        if "parity" in res and not res["parity"]["ok"]:
+            bad.append(f"also.{leg}.parity")
     return bad
 
 
 def also_spectrum16k(args, dev, rank: int):
-    """A short leg of BASELINE configs[3] attached to the default line so that the driver-timed record
-    carries it: ONE 16,384-frame chunk (1 GiB of N=16384 real frames, generated on the device) through
-    the fused Hann + FFT + one-sided amplitude kernel, a few steps, HIP events on the launch stream;
-    64 of its rows checked against the oracle.  98,308 algorithmic bytes per frame."""
+    """BASELINE configs[3] at its stated size, attached to the default line so that the driver-timed record carries
+    it: N = 16384, batch = 2^20 frames = 2^34 samples, fused Hann + FFT + one-sided amplitude, processed as a stream
+    of 64 chunks of 16,384 frames (one launch each) per step; HIP events on the launch stream around every step.
+    98,308 algorithmic bytes per frame.  The card has 288 GB: when ~100 GiB are free the WHOLE stream is
+    resident -- 64 GiB of distinct frames in, 32 GiB of amplitude rows out, nothing re-read -- otherwise (`resident`
+    false) every launch consumes the same 1-GiB chunk, which is far beyond the 256 MiB Infinity Cache either way.
+    64 rows drawn over the whole stream are checked against the oracle; the oracle's own fused path (applyWindow ->
+    FFT -> magnitude -> one-sided scaling, spectrum.ts:116-127, plan and window reused) is timed on 64 of the same
+    frames as this leg's CPU baseline."""
     from pragma_dsp_amd.batch import BatchedFft
-    n, chunk, steps = 16384, 16384, 20
+    n, chunk, chunks, steps = 16384, 16384, 64, 4
+    bins = n // 2 + 1
     torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    need = chunks * chunk * (n + bins) * 4
+    resident = (not args.also_reuse_chunk) and free_b > need + (12 << 30)
     plan = BatchedFft(n, dev)
-    x, _ = synth_batch(chunk, n, dev, seed=1337 + rank, complex_noise=False)
-    amp = torch.empty((chunk, n // 2 + 1), dtype=torch.float32, device=dev)
+    if resident:
+        xs = [synth_batch(chunk, n, dev, seed=1337 + rank + 7919 * c, complex_noise=False)[0] for c in range(chunks)]
+        amps = [torch.empty((chunk, bins), dtype=torch.float32, device=dev) for _ in range(chunks)]
+    else:
+        x0, _ = synth_batch(chunk, n, dev, seed=1337 + rank, complex_noise=False)
+        a0 = torch.empty((chunk, bins), dtype=torch.float32, device=dev)
+        xs, amps = [x0] * chunks, [a0] * chunks
     plan.window("hann")
     stream = torch.cuda.current_stream(dev)
-    t_ramp = time.perf_counter()  # the clocks fell back during the host-side parity leg: ramp again, untimed
+
+    def one_step():
+        for c in range(chunks):
+            plan.spectrum(xs[c], "hann", "one", out=amps[c])
+    t_ramp = time.perf_counter()  # the clocks fell back during the host-side legs: ramp again, untimed
+    one_step()
+    torch.cuda.synchronize(dev)
     while time.perf_counter() - t_ramp < args.ramp_seconds:
-        for _ in range(10):
-            plan.spectrum(x, "hann", "one", out=amp)
+        one_step()
         torch.cuda.synchronize(dev)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     evs[0].record(stream)
     for i in range(steps):
-        plan.spectrum(x, "hann", "one", out=amp)
+        one_step()
         evs[i + 1].record(stream)
     torch.cuda.synchronize(dev)
     ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
-    nbytes = (4 * n + 4 * (n // 2 + 1)) * chunk
-    avg = float(np.mean(ms))
-    res = {"config": "N=16384 fused hann+FFT+one-sided amplitude, one 16384-frame chunk (configs[3] shape)",
-           "kernel": "spectrum_dif16k_kernel<float, 2, false> (fused Hann)", "steps": steps, "ms": avg, "ms_min": float(np.min(ms)),
+    nbytes = (4 * n + 4 * bins) * chunk
+    step_ms = float(np.mean(ms))
+    avg = step_ms / chunks
+    res = {"config": {"workload": f"N=16384 batch={chunks * chunk} fused hann+FFT+one-sided amplitude, streamed as {chunks} chunks "
+                                  f"of {chunk} frames (configs[3])", "n": n, "batch": chunks * chunk,
+                      "chunks_per_step": chunks, "frames_per_chunk": chunk, "samples_per_step": chunks * chunk * n,
+                      "resident": resident,
+                      "note": ("the whole 2^20-frame stream is resident in HBM: 64 GiB of distinct frames in, 32 GiB out"
+                               if resident else "every launch consumes the same 1-GiB chunk of frames (64 GiB + 32 GiB did not fit beside the rest)")},
+           "kernel": "spectrum_dif16k_kernel<float, 2, false> (fused Hann)", "steps": steps,
+           "ms_per_step": step_ms, "ms_per_step_min": float(np.min(ms)), "ms": avg, "ms_min": float(np.min(ms)) / chunks,
            "GSample_per_s": chunk * n / (avg * 1e-3) / 1e9, "algorithmic_bytes_per_launch": nbytes,
+           "algorithmic_bytes_per_step": nbytes * chunks,
            "GBps": nbytes / (avg * 1e-3) / 1e9, "frac": nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     if not args.no_cpu_baseline:
         g = torch.Generator()
         g.manual_seed(1337)
-        sel = torch.randperm(chunk, generator=g)[:64].sort().values.to(dev)
-        res["parity"] = parity_vs_oracle("spectrum", (x[sel].cpu().numpy(),), (amp[sel].cpu().numpy().astype(np.float64),),
-                                         n, "hann")
-    del x, amp
+        pick = torch.randperm(chunks * chunk, generator=g)[:64].sort().values.tolist()
+        hx = np.stack([xs[r // chunk][r % chunk].cpu().numpy() for r in pick])
+        ha = np.stack([amps[r // chunk][r % chunk].cpu().numpy() for r in pick]).astype(np.float64)
+        res["parity"] = parity_vs_oracle("spectrum", (hx,), (ha,), n, "hann")
+        res["parity"]["rows_drawn_from"] = "the whole 2^20-frame stream" if resident else "the one resident chunk"
+        del xs, amps
+        torch.cuda.empty_cache()
+        res["cpu_baseline"] = cpu_baseline_spectrum(hx, n, "hann")
+    return res
+
+
+def cpu_baseline_spectrum(frames: np.ndarray, n: int, window: str, target_s: float = 6.0):
+    """The oracle's fused window + FFT + magnitude + one-sided scaling (oracle_spectrum_batch: spectrum.ts:116-127
+    restated, f64 scalar C, plan and window built once and reused, 1 thread) timed on a bounded sample of the
+    GPU leg's own frames."""
+    import oracle
+    plan = oracle.Plan(n)
+    win = oracle.create_window(window, n)
+    x = np.ascontiguousarray(frames, dtype=np.float64)
+    plan.spectrum_batch(x[:8], window=win)  # warm-up
+    t0 = time.perf_counter()
+    plan.spectrum_batch(x, window=win)
+    per = (time.perf_counter() - t0) / x.shape[0]
+    reps = max(1, int(target_s / (per * x.shape[0])))
+    chk = 0.0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        amp, _, _ = plan.spectrum_batch(x, window=win)
+        chk += float(amp[0, 1])
+    sec = time.perf_counter() - t0
+    done = reps * x.shape[0]
+    return {"value": done * n / sec / 1e9, "unit": "GSample/s", "cores": 1, "kind": "port",
+            "frames_per_s": done / sec, "checksum": chk,
+            "sample": f"{done} frames of N={n} ({x.shape[0]} distinct frames of the GPU stream x {reps} passes), {sec:.1f} s, "
+                      f"f64 scalar C -O2: applyWindow + FFT + magnitude + one-sided scaling, plan and window reused; "
+                      f"host has {os.cpu_count()} cpus"}
+
+
+def also_fft4096_f64(args, dev, rank: int, re32, im32):
+    """The headline shape in the REFERENCE'S OWN precision (src/core/fft.ts:1-14: Float64Array end to end): the same
+    65,536 x 4096 rows as doubles through pdsp_fft_forward_complex_f64 -- 32 algorithmic bytes per sample, 8 GiB per
+    launch -- HIP events on the launch stream, 64 rows against the f64 oracle at 1e-12 of the row's max."""
+    from pragma_dsp_amd.batch import BatchedFft
+    n, steps = 4096, 10
+    batch = re32.shape[0]
+    torch.cuda.empty_cache()
+    plan = BatchedFft(n, dev, dtype=torch.float64)
+    re, im = re32.double(), im32.double()
+    ore, oim = torch.empty_like(re), torch.empty_like(im)
+    stream = torch.cuda.current_stream(dev)
+    t_ramp = time.perf_counter()
+    plan.forward(re, im, out=(ore, oim))
+    torch.cuda.synchronize(dev)
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        for _ in range(5):
+            plan.forward(re, im, out=(ore, oim))
+        torch.cuda.synchronize(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record(stream)
+    for i in range(steps):
+        plan.forward(re, im, out=(ore, oim))
+        evs[i + 1].record(stream)
+    torch.cuda.synchronize(dev)
+    ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    avg = float(np.mean(ms))
+    nbytes = 32 * batch * n
+    res = {"config": {"workload": f"N=4096 batch={batch} Radix2Fft.forwardComplex f64 planar complex (configs[2]'s shape in the "
+                                  f"reference's own precision)", "n": n, "batch": batch},
+           "kernel": "fft_stockham_kernel<double, 12, LoadComplex, StoreComplex>", "dtype": "f64", "steps": steps,
+           "ms": avg, "ms_min": float(np.min(ms)), "GSample_per_s": batch * n / (avg * 1e-3) / 1e9,
+           "algorithmic_bytes_per_launch": nbytes, "GBps": nbytes / (avg * 1e-3) / 1e9,
+           "frac": nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    if not args.no_cpu_baseline:
+        import oracle
+        g = torch.Generator()
+        g.manual_seed(1337)
+        sel = torch.randperm(batch, generator=g)[:64].sort().values.to(dev)
+        wre, wim = oracle.Plan(n).forward_complex(re[sel].cpu().numpy(), im[sel].cpu().numpy())
+        want = wre + 1j * wim
+        got = ore[sel].cpu().numpy() + 1j * oim[sel].cpu().numpy()
+        err = np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)
+        res["parity"] = {"rows": 64, "max_rel_err": float(err.max()), "tolerance": 1e-12, "ok": bool(err.max() <= 1e-12),
+                         "against": "oracle/pdsp_oracle.c (f64), rows drawn with seed 1337"}
+    del re, im, ore, oim
+    torch.cuda.empty_cache()
     return res
 
 

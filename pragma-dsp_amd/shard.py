@@ -41,13 +41,15 @@ def my_rows(batch: int, rank: int | None = None, world: int | None = None) -> tu
     return shard_bounds(batch, world)[rank]
 
 
-def gather_rows(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, batch: int, group=None, force_collective: bool = False) -> torch.Tensor:
     """All-gather the per-rank slabs `local` ([rows_r, ...]) into the full [batch, ...]
     tensor on every rank, in rank order.  Ragged shards are padded to the largest one
     for the collective (one all_gather_into_tensor = one RCCL ring over xGMI) and
-    trimmed afterwards.  A single process returns `local` itself."""
+    trimmed afterwards.  A single process returns `local` itself -- unless
+    `force_collective` asks for the collective call even in a group of one (bench.py's
+    `--rccl-selftest`: the same all_gather_into_tensor on one card)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         if local.shape[0] != batch:
             raise ValueError(f"local slab has {local.shape[0]} rows, batch is {batch}")
         return local

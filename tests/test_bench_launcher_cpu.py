@@ -65,6 +65,70 @@ def test_driver_form_torch_distributed_run():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["gather_ok"] is True
 
 
+def test_abandoned_exchange_exits_5_on_every_rank_and_the_line_survives():
+    """A gather that never returns (rank 1 never joins it) is abandoned by the watchdog after --gather-timeout:
+    rank 0's line is printed with gather.error and relayed, and the status is 5 -- a hang is a finding, not a
+    success (VERDICT r2 item 1b / ADVICE r2 medium)."""
+    p = _run(["--gpus", "2", "--dry-run", "--batch", "64", "--simulate-hang", "--gather-timeout", "3"])
+    assert p.returncode == 5, (p.returncode, p.stderr[-2000:])
+    assert "rank 0 exited with 5" in p.stderr and "rank 1 exited with 5" in p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "abandoned" in d["gather"]["error"] and "gather_ok" not in d
+
+
+def test_abandoned_exchange_in_the_driver_form_is_nonzero_too():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--dry-run",
+                        "--batch", "64", "--simulate-hang", "--gather-timeout", "3"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "abandoned" in json.loads(lines[0])["gather"]["error"]
+
+
+def test_world_of_one_watchdog_status():
+    p = _run(["--dry-run", "--batch", "64", "--simulate-hang", "--gather-timeout", "2"])
+    assert p.returncode == 5
+    assert "abandoned" in json.loads(p.stdout.strip().splitlines()[-1])["gather"]["error"]
+
+
+def test_rank0_stdout_larger_than_a_pipe_buffer_does_not_stall_the_launch():
+    """rank 0's stdout used to be a pipe read only after exit; 64 KiB of stray output blocked the child
+    until --launch-timeout.  It is a file now."""
+    p = _run(["--gpus", "2", "--dry-run", "--batch", "64", "--stdout-noise", "300000", "--launch-timeout", "120"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["gather_ok"] is True
+
+
+def test_a_line_printed_before_a_failure_is_still_relayed():
+    """The measurement survives a later failure: rank 0's line is relayed even when the launch ends non-zero."""
+    import tempfile
+    child = "\n".join(["import os, sys",
+                       "if os.environ['RANK'] == '0':",
+                       "    print('{\"value\": 1}', flush=True)",
+                       "sys.exit(5)", ""])
+    driver = "\n".join(["import sys",
+                        "sys.path.insert(0, sys.argv[1])",
+                        "import bench",
+                        "args = bench.parse_args(['--gpus', '2', '--launch-timeout', '60', '--dry-run'])",
+                        "bench.__file__ = sys.argv[2]  # launch_ranks starts children of `__file__`",
+                        "raise SystemExit(bench.launch_ranks(args, []))", ""])
+    with tempfile.TemporaryDirectory() as td:
+        cpath = os.path.join(td, "_child.py")
+        with open(cpath, "w") as f:
+            f.write(child)
+        p = subprocess.run([sys.executable, "-c", driver, ROOT, cpath], capture_output=True, text=True, timeout=120,
+                           env=_env(), cwd=ROOT)
+    assert p.returncode == 5, (p.returncode, p.stderr[-1000:])
+    assert p.stdout.strip() == '{"value": 1}'
+
+
 def test_single_process_without_gpu_fails_loudly():
     """No CPU fallback: without a GPU the real workload refuses to run (and prints no result line)."""
     import torch
