@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/pdsp_hip.h"
+#include "../../include/pdsp_hip_dev.h"
 #include "pdsp_fft_kernel.h"
 
 namespace {
@@ -30,6 +31,8 @@ int g_fused_window = 1;
 int g_twopass = 1;       // pdsp_set_twopass: 2^15 <= N <= 2^18 f32 transforms in two passes (balanced factors)  // pdsp_set_fused_window: plan-owned cosine-sum windows evaluated in the kernel
 int g_split8k_f32 = 0;  // f32 N = 8192 rows on fft_split2_kernel too (A/B: pdsp_set_split16k bit 1)
 int g_staged_small = 1;
+int g_amp_pitch = 0;    // pdsp_set_amp_pitch (experiment): row pitch, in values, of spectrum_dif16k_kernel's amplitude rows
+int g_real_packed = 1;  // pdsp_set_real_packed: Radix2Fft.forward rows of 512 <= N <= 16384 on fft_real_kernel
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -298,10 +301,13 @@ hipError_t launch_rows(const Tables<T> &t, int log2n, const LD &ld, const ST &st
   }
   // N = 8192: measured on one box, f64 C2C 4.35 -> 5.80 TB/s, f64 real-in 4.0 -> 5.6, f32 real-in 5.4 -> 5.7,
   // f32 C2C a wash (stays on the single-pass kernel)
-  if (log2n == 13 && (sizeof(T) == 8 || !LD::kHasIm || g_split8k_f32) && g_split16k && aligned16 && t.tws2 && t.tw12) {
-    hipLaunchKernelGGL((pdsp::fft_split2_kernel<T, LD, ST>), dim3((unsigned)batch), dim3(256), 0, s, ld, st, t.tw12,
-                       t.tws2, batch);
-    return hipGetLastError();
+  // (f64 real rows run on fft_real_kernel; their LoadReal form of this kernel spilled 37 registers and is not built)
+  if constexpr (!(sizeof(T) == 8 && !LD::kHasIm)) {
+    if (log2n == 13 && (sizeof(T) == 8 || !LD::kHasIm || g_split8k_f32) && g_split16k && aligned16 && t.tws2 && t.tw12) {
+      hipLaunchKernelGGL((pdsp::fft_split2_kernel<T, LD, ST>), dim3((unsigned)batch), dim3(256), 0, s, ld, st, t.tw12,
+                         t.tws2, batch);
+      return hipGetLastError();
+    }
   }
   return launch_fft<T>(log2n, ld, st, t.tw, batch, s);
 }
@@ -357,6 +363,24 @@ hipError_t launch_packed(int log2m, A... a) {
     return launch_packed_one<T, L>(a...);
     PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7) PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12)
     PDSP_CASE(13)
+#undef PDSP_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+template <typename T>
+hipError_t launch_real(int log2m, const T *x, T *ore, T *oim, T scale, const typename pdsp::vec2<T>::type *tw,
+                       const typename pdsp::vec2<T>::type *twr, long long batch, hipStream_t s) {
+  switch (log2m) {
+#define PDSP_CASE(L)                                                                                              \
+  case L: {                                                                                                       \
+    using TR = pdsp::FftTraits<L, 4>;                                                                             \
+    hipLaunchKernelGGL((pdsp::fft_real_kernel<T, L>), dim3((unsigned)((batch + TR::ROWS - 1) / TR::ROWS)), dim3(TR::WG), \
+                       0, s, x, ore, oim, scale, tw, twr, batch);                                                 \
+    return hipGetLastError();                                                                                     \
+  }
+    PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12) PDSP_CASE(13)
 #undef PDSP_CASE
     default:
       return hipErrorInvalidValue;
@@ -676,6 +700,20 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
                 pdsp_max_size((int)sizeof(T)));
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
+  // Radix2Fft.forward rows (real input) of 512 <= N <= 16384 in f64 -- the drop-in's default arithmetic: one
+  // N/2-point packed-real transform per row and the split to X[k], X[k + N/2] (fft_real_kernel) -- half the
+  // butterflies of the complex kernel on (x, 0), the same store streams, and N = 16384 stays in one pass.  Measured
+  // against the complex kernels (tools/ab_real_packed.py --f64, one process): N = 512 ... 4096 +1 ... +9 %,
+  // 8192 4.93 -> 6.57 TB/s, 16384 (was a four-step transform) 1.60 -> 5.18.  In f32 the same kernel measured
+  // 0.98 ... 1.01 of the complex kernels (both at the box's copy ceiling) and 0.74 at N = 512, so f32 real rows stay
+  // where they were and the f32 form is not built.  Rows aligned to a sample pair.
+  if constexpr (sizeof(T) == 8) {
+    if (!im_in && g_real_packed && plan->log2n >= 9 && plan->log2n <= 14 && t.tw_half && t.twr &&
+        ((uintptr_t)re_in & (2 * sizeof(T) - 1)) == 0) {
+      PDSP_HIP_TRY(launch_real<T>(plan->log2n - 1, re_in, re_out, im_out, scale, t.tw_half, t.twr, batch, s));
+      return PDSP_OK;
+    }
+  }
   if constexpr (sizeof(T) == 4) {
     // N = 2^15 / 2^16 out of place: ONE pass over HBM by 2 / 4 sibling workgroups per transform that share their
     // XCD's L2 (fft_paired_kernel).  In place the siblings would overwrite each other's input: tile passes then.
@@ -1427,7 +1465,8 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
         const int mode = wmode;
 #define PDSP_DIF(W, P)                                                                                              \
   hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames,  \
-                     window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch)
+                     window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch,        \
+                     (long long)(g_amp_pitch > bins ? g_amp_pitch : bins))
 #define PDSP_DIF_P(W)    \
   do {                   \
     if (pk) PDSP_DIF(W, true); \
@@ -1670,6 +1709,18 @@ PDSP_DEFINE_PLAN_WINDOW(f64, double)
 int pdsp_set_staged_small(int enabled) {
   const int prev = g_staged_small;
   g_staged_small = enabled ? 1 : 0;
+  return prev;
+}
+
+int pdsp_set_amp_pitch(int values) {
+  const int prev = g_amp_pitch;
+  g_amp_pitch = values > 0 ? values : 0;
+  return prev;
+}
+
+int pdsp_set_real_packed(int enabled) {
+  const int prev = g_real_packed;
+  g_real_packed = enabled ? 1 : 0;
   return prev;
 }
 

@@ -1201,6 +1201,84 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   }
 }
 
+// Radix2Fft.forward(real input) (src/core/fft.ts:77-79: imaginary part taken as zero) on rows of N = 2M real
+// samples through the packed-real identity, with the FULL complex spectrum written to both planes.
+//   z[m] = x[2m] + i x[2m+1] (an 8-byte view of the row),  Z = FFT_M(z)  -- half the butterflies, LDS traffic and
+//   twiddles of running the complex kernel on (x, 0), and the row arrives as 8-byte instead of 4-byte loads;
+//   E[k] = (Z[k] + conj Z[M-k]) / 2,  O[k] = (Z[k] - conj Z[M-k]) / (2i)   (transforms of the even / odd samples)
+//   X[k] = E[k] + W_N^k O[k],  X[k + M] = E[k] - W_N^k O[k],   0 <= k < M.
+// Every thread forms X[k], X[k + M] for its OWN sixteen k = tid + TP q from (Z[k], Z[M-k]) read back from LDS: each
+// pair (k, M-k) is split twice, once from either side -- six packed instructions per k -- so that both planes
+// leave as the same forward unit-stride streams `row N + tid + TP q` the complex kernel writes.  (Round 2 tried the
+// split that writes X[k] and its mirror X[N-k] = conj X[k] from one side: four store streams per plane in two
+// directions, slower than the complex kernel at every size)
+//   tw = radix table of the M-point transform (Tables::tw_half), twr[k] = W_N^k (Tables::twr), scale = 1.
+// Rows must be aligned to one pair of samples.  In place row for row is fine: a workgroup loads its rows before it
+// stores.  Dispatched for f64 rows (the drop-in's default arithmetic), where it wins at every size and most where
+// the complex kernel is short of registers or LDS (N = 8192: 61.6 -> 82 % of 8 TB/s; N = 16384: one pass instead of
+// a four-step transform, 20 -> 65 %).  In f32 both forms run at the box's copy ceiling (A/B 0.98 ... 1.01), so f32
+// real rows keep the complex kernels and no f32 instance is built.
+template <typename T, int LOG2M>
+__global__ void __launch_bounds__(kPackedWG<LOG2M>)
+fft_real_kernel(const T *__restrict__ xin, T *__restrict__ ore, T *__restrict__ oim, const T scale,
+                const typename vec2<T>::type *__restrict__ tw, const typename vec2<T>::type *__restrict__ twr,
+                const long long batch) {
+  constexpr int LOG2E = 4;
+  using TR = FftTraits<LOG2M, LOG2E>;
+  constexpr int E = TR::E, TP = TR::TP, M = TR::N;
+  static_assert(LOG2M >= 8 && TP % 16 == 0, "N >= 512: register twiddle bases, constant LDS offsets");
+  static_assert(packed_log2e(LOG2M) == LOG2E, "Tables::tw_half is built for sixteen points per thread");
+  __shared__ cx<T> lds[TR::LDS_ELEMS];
+
+  const int tid = (int)(threadIdx.x % TP);
+  const int rloc = (int)(threadIdx.x / TP);
+  const long long row_raw = (long long)blockIdx.x * TR::ROWS + rloc;
+  const bool live = row_raw < batch;
+  const long long row = uniform_row<TP>(live ? row_raw : batch - 1);
+  cx<T> *const lrow = lds + rloc * TR::LROW;
+
+  RegTwiddles<T, LOG2M, LOG2E> twf;
+  cx<T> twk0;
+  if constexpr (PDSP_TABLES_FIRST_C2C) {
+    twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+    twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
+    load_order_fence();
+  }
+  const cx<T> *const x2 = reinterpret_cast<const cx<T> *>(xin + (size_t)row * (size_t)(2 * M));
+  cx<T> x[E];
+  static_for<E>([&](auto q) { x[q] = ld_stream(x2 + TP * q + (unsigned)tid); });
+  if constexpr (!PDSP_TABLES_FIRST_C2C) {
+    twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
+    twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];  // W_N^tid; W_N^(tid + TP q) = twk0 * W_32^q (N = 32 TP)
+  }
+
+  fft_passes<T, LOG2M, true, LOG2E>(x, lrow, twf, tid);  // Z in LDS, natural order
+  __syncthreads();
+
+  // LDS: Z[k] at pad(tid) + q cpad(TP); Z[M-k] at pad(M - tid) - q cpad(TP); Z[M] == Z[0]
+  const cx<T> *const zlo = lrow + lds_pad(tid);
+  const cx<T> *const zhi = lrow + lds_pad(M - tid);
+  const cx<T> *const zhi0 = lrow + lds_pad((M - tid) & (M - 1));
+  T *const rre = ore + (size_t)row * (size_t)(2 * M), *const rim = oim + (size_t)row * (size_t)(2 * M);
+  const T h = T(0.5) * scale;
+  static_for<E>([&](auto qc) {
+    constexpr int q = qc;
+    const cx<T> z = zlo[cpad(TP * q)];
+    const cx<T> zp = q == 0 ? zhi0[0] : *(zhi - cpad(TP * q));
+    const cx<T> w = mul_w32<T, q>(twk0);
+    const cx<T> s = z + conj(zp);
+    const cx<T> p = cmul(z - conj(zp), w);             // 2i W^k O[k]
+    const cx<T> xa = add_mul_neg_i(s, p) * h;          // X[k]     = (S - i P) / 2
+    const cx<T> xb = add_mul_pos_i(s, p) * h;          // X[k + M] = (S + i P) / 2
+    if (live) {
+      st_stream(xa.x, rre + TP * q + (unsigned)tid);
+      st_stream(xa.y, rim + TP * q + (unsigned)tid);
+      st_stream(xb.x, rre + M + TP * q + (unsigned)tid);
+      st_stream(xb.y, rim + M + TP * q + (unsigned)tid);
+    }
+  });
+}
+
 // ---- four-step path for N beyond the single-pass LDS limit --------------------
 // N = N1 * N2 with N2 = the largest single-pass size and 2 <= N1 <= 16.  Input index
 // n = n1*N2 + n2, output index k = k1 + N1*k2.
@@ -1547,6 +1625,9 @@ fft_split4_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
       b[q] = cx<T>{r0.z, r0.w};
       c[q] = cx<T>{r1.x, r1.y};
       d[q] = cx<T>{r1.z, r1.w};
+      // window table: a step holds four 16-byte loads; left alone hipcc hoists all sixteen steps' loads above the
+      // first product (256 registers in flight beside the 128 of a..d: 10 spilled).  Four steps at a time.
+      if constexpr (LD::kWin == 1 && q % 4 == 3) load_order_fence();
     });
   } else if constexpr (LD::kHasIm) {
     const V4 *const r4 = reinterpret_cast<const V4 *>(ld.plane_re() + (size_t)row * N);
@@ -1786,7 +1867,8 @@ fft_split2_kernel(const LD ld, const ST st, const typename vec2<T>::type *__rest
   cx<T> a[E], b[E];
   // f64 complex rows: 64 data registers + 24 twiddle-base registers + the butterfly's temporaries do not
   // fit 256 VGPRs (81 spilled); reading the twiddles from the L2-resident table at each use instead
-  // measured 4.36 -> 5.80 TB/s.  f64 real rows fit (and measure 5.6 vs 5.35 with the bases in registers).
+  // measured 4.36 -> 5.80 TB/s.  (f64 REAL rows no longer come here: with the bases in registers they spilled 37
+  // registers in round 2's build; they run on fft_real_kernel, one 4096-point packed transform, at 6.5 TB/s.)
   constexpr bool kTableTw = sizeof(T) == 8 && LD::kHasIm;
   std::conditional_t<kTableTw, TableTwiddles<T, 12>, RegTwiddles<T, 12>> twf;
   cx<T> w1;
@@ -1868,7 +1950,8 @@ __global__ void __launch_bounds__(256, PDSP_DIF16K_WAVES)
 spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, const WinFused wf, const long long stride,
                        const typename vec2<T>::type *__restrict__ tw12,
                        const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp, const T s_edge,
-                       const T s_mid, PeakRec *__restrict__ peaks, const T freq_scale, const long long batch) {
+                       const T s_mid, PeakRec *__restrict__ peaks, const T freq_scale, const long long batch,
+                       const long long amp_pitch) {
   constexpr bool HAS_WIN = WIN == 1;
   static_assert(WIN <= 1 || sizeof(T) == 4, "the fused window is the f32 path's (f64 keeps the f64-built table)");
   using TR = FftTraits<12>;
@@ -1969,7 +2052,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   const cx<T> umid = a[E / 2];  // thread 0: U[2048] = Z[4096], the bin that pairs with itself
   __syncthreads();
 
-  T *const arow = amp + (size_t)row * (size_t)(M + 1);
+  T *const arow = amp + (size_t)row * (size_t)amp_pitch;  // M + 1 = packed rows; a larger pitch aligns every row
   const bool store_amp = !PEAK || amp != nullptr;
   PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);

@@ -12,19 +12,23 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "pdsp_hip.h")).read()
+def header_symbols(name="pdsp_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     return sorted(set(re.findall(r"PDSP_API\s+[\w\s\*]+?\b(pdsp_\w+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol(pdsp):
     syms = header_symbols()
-    assert len(syms) >= 25
+    dev = header_symbols("pdsp_hip_dev.h")
+    assert len(syms) >= 25 and len(dev) >= 4
     raw = C.CDLL(pdsp.LIB_PATH)
-    for s in syms:
-        assert hasattr(raw, s), f"{s} declared in include/pdsp_hip.h but not exported"
+    for s in syms + dev:
+        assert hasattr(raw, s), f"{s} declared in include/*.h but not exported"
+    # the boundary header carries no development switch: only the user-facing precision knob
+    assert [s for s in syms if s.startswith("pdsp_set_")] == ["pdsp_set_host_precision"]
+    assert all(s.startswith("pdsp_set_") for s in dev) and not set(dev) & set(syms)
     # and the ctypes binding covers all of them
-    assert set(syms) == set(pdsp.lib._pdsp_symbols)
+    assert set(syms) | set(dev) == set(pdsp.lib._pdsp_symbols)
     assert pdsp.lib.pdsp_version() >= 100
     assert pdsp.lib.pdsp_max_size(4) == 1 << 28 and pdsp.lib.pdsp_max_size(8) == 1 << 26
 

@@ -197,6 +197,7 @@ def test_split4_kernel_n16384_vs_single_pass_vs_oracle(pdsp, oracle_mod, batch):
     out = {}
     for mode in (1, 0):
         prev = pdsp.lib.pdsp_set_split16k(mode)
+        prev_rp = pdsp.lib.pdsp_set_real_packed(0)  # real rows on this kernel's LoadReal form, not on fft_real_kernel
         try:
             guard = torch.full((batch + 2, n), 777.0, device="cuda")
             ore, oim = guard[1:batch + 1], torch.empty((batch, n), device="cuda")
@@ -206,6 +207,7 @@ def test_split4_kernel_n16384_vs_single_pass_vs_oracle(pdsp, oracle_mod, batch):
             torch.cuda.synchronize()
         finally:
             pdsp.lib.pdsp_set_split16k(prev)
+            pdsp.lib.pdsp_set_real_packed(prev_rp)
         assert bool((guard[0] == 777.0).all()) and bool((guard[-1] == 777.0).all())
         got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
         assert rel_err(got, wre + 1j * wim) <= TOL
@@ -242,6 +244,7 @@ def test_split2_kernel_n8192_vs_single_pass_vs_oracle(pdsp, oracle_mod, dtype_na
     out = {}
     for mode in (3, 0):
         prev = pdsp.lib.pdsp_set_split16k(mode)
+        prev_rp = pdsp.lib.pdsp_set_real_packed(0)  # real rows on this kernel's LoadReal form, not on fft_real_kernel
         try:
             guard = torch.full((batch + 2, n), 777.0, device="cuda", dtype=dt)
             ore, oim = guard[1:batch + 1], torch.empty((batch, n), device="cuda", dtype=dt)
@@ -251,6 +254,7 @@ def test_split2_kernel_n8192_vs_single_pass_vs_oracle(pdsp, oracle_mod, dtype_na
             torch.cuda.synchronize()
         finally:
             pdsp.lib.pdsp_set_split16k(prev)
+            pdsp.lib.pdsp_set_real_packed(prev_rp)
         assert bool((guard[0] == 777.0).all()) and bool((guard[-1] == 777.0).all())
         got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
         assert rel_err(got, wre + 1j * wim) <= tol
