@@ -70,7 +70,10 @@ class BatchedFft:
         self._h = handle
         self._windows = {}
 
-    def __del__(self):
+    def close(self):
+        """Destroys the native plan now (also done when the object is collected).  For a size beyond the single-pass
+        limit this also hands the engine's scratch planes -- as large as the largest such transform run -- back to
+        the device, where the caller's allocator can use them again."""
         h = getattr(self, "_h", None)
         if h:
             try:
@@ -78,6 +81,17 @@ class BatchedFft:
             except Exception:
                 pass
             self._h = None
+            self._windows = {}
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     # -- helpers -------------------------------------------------------------
     def _check(self, t, name, last=None):

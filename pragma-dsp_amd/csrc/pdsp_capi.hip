@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <new>
@@ -80,11 +81,13 @@ hipMemPool_t scratch_pool() {
   }
   return g_scratch_pool[dev];
 }
-void trim_scratch_pools() {
-  std::lock_guard<std::mutex> lk(g_scratch_pool_mu);
-  for (hipMemPool_t pool : g_scratch_pool)
-    if (pool) (void)hipMemPoolTrimTo(pool, 0);
-}
+void trim_scratch_pools();
+
+// Bytes of scratch planes this process has drawn from the pools since they were last trimmed: pdsp_plan_destroy()
+// hands the pools' unused memory back to the device when a plan that needs scratch (N beyond the single-pass
+// limit) goes away and anything was drawn -- otherwise GiBs of HBM stay pinned where the caller's allocator
+// (PyTorch's, say) cannot see them, long after the last large transform.
+std::atomic<unsigned long long> g_scratch_drawn{0};
 
 struct StreamScratch {
   void *p = nullptr;
@@ -93,6 +96,7 @@ struct StreamScratch {
   StreamScratch(const StreamScratch &) = delete;
   StreamScratch &operator=(const StreamScratch &) = delete;
   hipError_t alloc(size_t bytes) {
+    g_scratch_drawn += bytes;
     if (hipMemPool_t pool = scratch_pool()) return hipMallocFromPoolAsync(&p, bytes, pool, s);
     return hipMallocAsync(&p, bytes, s);  // no pool of our own on this device: the default one
   }
@@ -100,6 +104,13 @@ struct StreamScratch {
     if (p) (void)hipFreeAsync(p, s);
   }
 };
+
+void trim_scratch_pools() {
+  std::lock_guard<std::mutex> lk(g_scratch_pool_mu);
+  for (hipMemPool_t pool : g_scratch_pool)
+    if (pool) (void)hipMemPoolTrimTo(pool, 0);
+  g_scratch_drawn = 0;
+}
 
 struct DeviceGuard {
   int prev = -1;
@@ -281,6 +292,22 @@ hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const typename pdsp
     return launch_one<T, L>(ld, st, tw, batch, s);
     PDSP_CASE(0) PDSP_CASE(1) PDSP_CASE(2) PDSP_CASE(3) PDSP_CASE(4) PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7)
     PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12) PDSP_CASE(13) PDSP_CASE(14)
+#undef PDSP_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+// The same for N <= 32 only (spectrum() of frames below the packed-real path's sizes: LoadFrameWindowed /
+// StoreAmplitude are not instantiated for the sizes that never take them).
+template <typename T, class LD, class ST>
+hipError_t launch_fft_small(int log2n, const LD &ld, const ST &st, const typename pdsp::vec2<T>::type *tw, long long batch,
+                            hipStream_t s) {
+  switch (log2n) {
+#define PDSP_CASE(L) \
+  case L:            \
+    return launch_one<T, L>(ld, st, tw, batch, s);
+    PDSP_CASE(0) PDSP_CASE(1) PDSP_CASE(2) PDSP_CASE(3) PDSP_CASE(4) PDSP_CASE(5)
 #undef PDSP_CASE
     default:
       return hipErrorInvalidValue;
@@ -688,6 +715,17 @@ int tilepass_complex(const pdsp_plan *plan, long long batch, const T *re_in, con
                            in_batch ? in_batch : plan->n, re_out, im_out, scale, s1_re, s1_im, s2_re, s2_im, s);
 }
 
+// Do any of the output planes share bytes with any of the input planes?  Byte ranges, not pointer equality: an
+// output that starts one row into the input buffer overlaps it too.  The multi-pass paths use the output planes as
+// their first scratch pair only when this is false.
+template <typename T>
+bool planes_overlap(const T *re_in, const T *im_in, const T *re_out, const T *im_out, size_t plane_bytes) {
+  auto hit = [&](const T *a, const T *b) {
+    return a && b && (const char *)a < (const char *)b + plane_bytes && (const char *)b < (const char *)a + plane_bytes;
+  };
+  return hit(re_in, re_out) || hit(re_in, im_out) || hit(im_in, re_out) || hit(im_in, im_out);
+}
+
 template <typename T>
 int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out, T scale,
                 hipStream_t s) {
@@ -720,11 +758,7 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
     // pdsp_set_twopass: any value but 1 keeps the tile passes (5: their current form) -- A/B tests.
     if ((plan->log2n == 15 || plan->log2n == 16) && g_twopass == 1 && t.tw12 && t.tws4 && t.twa && t.twb &&
         (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {
-      const size_t plane_bytes = (size_t)batch * (size_t)plan->n * sizeof(T);
-      auto overlaps = [&](const T *a, const T *b) {
-        return a && b && (const char *)a < (const char *)b + plane_bytes && (const char *)b < (const char *)a + plane_bytes;
-      };
-      if (!overlaps(re_in, re_out) && !overlaps(re_in, im_out) && !overlaps(im_in, re_out) && !overlaps(im_in, im_out)) {
+      if (!planes_overlap(re_in, im_in, re_out, im_out, (size_t)batch * (size_t)plan->n * sizeof(T))) {
         const int lp = plan->log2n - 14;
         const long long blocks = ((batch + 7) / 8) * 8 * (1LL << lp);
         if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
@@ -750,9 +784,9 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
     if (t.tp_np && (g_twopass & 1) &&
         (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {
       const size_t plane = (size_t)batch * (size_t)plan->n;
-      const bool aliased = re_out == re_in || re_out == im_in || im_out == re_in || im_out == im_in;
+      const bool aliased = planes_overlap(re_in, im_in, re_out, im_out, plane * sizeof(T));
       // two passes: one scratch pair.  Three passes: the output planes double as the first scratch pair
-      // unless they alias the input.
+      // unless they share bytes with the input (equal pointers or a partial overlap).
       const int pairs = t.tp_np == 2 ? 1 : (aliased ? 2 : 1);
       StreamScratch mem(s);
       PDSP_HIP_TRY(mem.alloc((size_t)pairs * 2 * plane * sizeof(T)));
@@ -765,7 +799,7 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
   }
   if (t.log2n1 > pdsp::kMaxLog2N1) {  // general four-step: the output planes double as the first scratch pair
     const size_t plane = (size_t)batch * (size_t)plan->n;
-    const bool aliased = re_out == re_in || re_out == im_in || im_out == re_in || im_out == im_in;
+    const bool aliased = planes_overlap(re_in, im_in, re_out, im_out, plane * sizeof(T));
     StreamScratch mem(s);
     PDSP_HIP_TRY(mem.alloc((aliased ? 4 : 2) * plane * sizeof(T)));
     T *const scratch = (T *)mem.p;
@@ -1375,7 +1409,11 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
       return PDSP_OK;
     }
   }
-  if (t.log2n1 > 0) {  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in the last pass
+  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in the last pass.  (Not where the packed-real
+  // tables exist: f64 frames of N = 16384 are ONE 8192-point packed transform -- spectrum_packed_kernel<double, 13> --
+  // although the complex f64 transform of that size is a four-step one.  Round 2 sent them through the four-step
+  // path by this test's order.)
+  if (t.log2n1 > 0 && !t.tw_half) {
     const bool big = t.log2n1 > pdsp::kMaxLog2N1;  // general path: two scratch pairs
     T *amp = amp_out, *ph = phase_out;
     const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins, planes = big ? 4 : 2;
@@ -1401,11 +1439,12 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
     return rc;
   }
   constexpr uintptr_t kPairMask = 2 * sizeof(T) - 1;  // alignment of one (re, im) pair
-  if (t.tw_half && (window == nullptr || ((uintptr_t)window & kPairMask) == 0)) {
-    // packed-real path: N/2-point complex transform + Hermitian split (+ findPeak) fused with the store.
-    // fast variant: whole pair-aligned frames, one-sided, no phase rows (config 4's shape)
+  if (t.tw_half) {
+    // packed-real path (N >= 64): N/2-point complex transform + Hermitian split (+ findPeak) fused with the store.
+    // fast variant: whole pair-aligned frames (and window), one-sided, no phase rows (config 4's shape); the
+    // general variant takes any frame length, stride and alignment of frames and window
     const bool fast = ((uintptr_t)frames & kPairMask) == 0 && (frame_stride & 1) == 0 && used == n &&
-                      sides == PDSP_SIDES_ONE && phase_out == nullptr;
+                      sides == PDSP_SIDES_ONE && phase_out == nullptr && ((uintptr_t)window & kPairMask) == 0;
     // 64 <= N <= 512, amplitude only: contiguous frames staged in / amplitude rows staged out through LDS
     // (f32 only: in f64 the two LDS regions take 102 KB, one workgroup per CU, and measure slower than the direct kernel)
     if (sizeof(T) == 4 && fast && !peaks_out && !peak_idx_out && plan->log2n >= 6 && plan->log2n <= 9 && g_staged_small &&
@@ -1466,7 +1505,7 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
 #define PDSP_DIF(W, P)                                                                                              \
   hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames,  \
                      window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch,        \
-                     (long long)(g_amp_pitch > bins ? g_amp_pitch : bins))
+                     (long long)((g_amp_pitch < 0 ? -1 : 1) * (std::abs(g_amp_pitch) > bins ? std::abs(g_amp_pitch) : bins)))
 #define PDSP_DIF_P(W)    \
   do {                   \
     if (pk) PDSP_DIF(W, true); \
@@ -1490,8 +1529,8 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
                                     amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
                                     reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
   } else {
-    // complex kernel on (x, 0) for N < 64 or an unaligned window; peaks come from the stored rows
-    if (!t.tw) return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unaligned window at a size only the packed path holds");
+    // complex kernel on (x, 0) for N < 64 (the sizes without packed-real tables); peaks come from the stored rows
+    if (!t.tw || plan->log2n > 5) return fail(PDSP_ERR_UNSUPPORTED_SIZE, "no spectrum tables for size %lld", plan->n);
     if (plan->log2n >= 1 && plan->log2n <= 5 && g_staged_small && used == n && frame_stride == n && amp_out &&
         !phase_out && !peaks_out && ((uintptr_t)frames & (4 * sizeof(T) - 1)) == 0) {
       // 2 <= N <= 32, whole contiguous frames, amplitude only: one thread per frame, chunk staged through LDS
@@ -1518,10 +1557,10 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
                                (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1, s_edge, s_mid};
     if (window) {
       pdsp::LoadFrameWindowed<T, true> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, stream));
+      PDSP_HIP_TRY(launch_fft_small<T>(plan->log2n, ld, st, t.tw, batch, stream));
     } else {
       pdsp::LoadFrameWindowed<T, false> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, stream));
+      PDSP_HIP_TRY(launch_fft_small<T>(plan->log2n, ld, st, t.tw, batch, stream));
     }
     if (peaks_out) PDSP_HIP_TRY(launch_peaks<T>(amp, ph, bins, freq_scale, nullptr, peaks_out, batch, stream));
   }
@@ -1714,7 +1753,7 @@ int pdsp_set_staged_small(int enabled) {
 
 int pdsp_set_amp_pitch(int values) {
   const int prev = g_amp_pitch;
-  g_amp_pitch = values > 0 ? values : 0;
+  g_amp_pitch = values;  // < 0: the same pitch with the mirrored pairs as plain (not non-temporal) stores
   return prev;
 }
 
@@ -1865,10 +1904,16 @@ int pdsp_plan_destroy(pdsp_plan *plan) {
       (void)hipStreamSynchronize(plan->stream);
       (void)hipStreamDestroy(plan->stream);
     }
+    // a plan of a multi-pass size that drew scratch planes: the freed planes go back to the device with it
+    const bool multipass = plan->t32.log2n1 > 0 || plan->t64.log2n1 > 0;
     plan->t32.release();
     plan->t64.release();
     if (plan->d_stage) (void)hipFree(plan->d_stage);
     if (plan->h_stage) (void)hipHostFree(plan->h_stage);
+    if (multipass && g_scratch_drawn.load() > 0) {
+      (void)hipDeviceSynchronize();  // stream-ordered frees complete before the pool can let go of them
+      trim_scratch_pools();
+    }
   }
   delete plan;
   return PDSP_OK;

@@ -276,6 +276,19 @@ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
 // pad(a + c) == pad(a) + cpad(c) when c is a multiple of 16 (or a is and c < 16)
 constexpr int cpad(int c) { return c + c / 16; }
 
+// Bank conflicts of this layout, measured where the SQ counters do not saturate (2,048 rows per launch;
+// profiles/r03_lds_bank_conflicts_unsaturated.txt): the pad keeps the radix-16 SCATTER (ds_write_b64: 16-lane groups
+// over 32 banks) conflict-free but costs every READ-BACK a 2-way conflict -- a ds_read_b64 is served in two groups of
+// 32 lanes over 64 banks, and 32 consecutive points of a padded row span 33 slots, so lanes 0 and 31 of each group
+// meet on one bank pair: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = exactly 0.25 on fft_stockham_kernel<12> (64 of
+// 256 LDS-array cycles per wave), 0.20 on spectrum_dif16k_kernel.  No additive pad that is constant over 16-point
+// blocks can serve both sides (the scatter needs the pads of blocks 2s and 2s+1 to differ mod 16, the read-back
+// needs them equal mod 32).  An XOR swizzle, i ^ ((i >> 4) & 15), does -- built in round 3 for configs[2]'s kernel:
+// conflicts 524,288 -> 0 and LDS-array cycles -25 % per launch, at +59 vector instructions per thread (the
+// scatter's addresses are no longer base + constant) and 97 instead of 70 VGPRs; time 0.6681 vs 0.6689 ms, board
+// power 1,390 vs 1,388 W (tools' one-process A/B, profiles/r03_experiments/ab_lds_swizzle_*): the conflict cycles
+// are neither on the critical path nor in the power budget of an HBM-bound kernel, so the padded form stays and
+// the swizzled one was removed again.
 // A transform owned by >= 64 threads has one row per wave: tell the compiler the row
 // is wave-uniform so row bases live in SGPRs (batch < 2^31 is checked on the host).
 template <int TP>
@@ -970,9 +983,12 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     if constexpr (kAdj) tb = reinterpret_cast<const V4 *>(twr)[(unsigned)tid];
     else twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
     if constexpr (WIN >= 2) wb4 = reinterpret_cast<const V4 *>(wf.base)[(unsigned)tid];
-    if constexpr (HAS_WIN) {
+    if constexpr (HAS_WIN && FAST) {
       const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
       static_for<E>([&](auto q) { wv[q] = (w2 + TP * q)[(unsigned)tid]; });
+    } else if constexpr (HAS_WIN) {
+      // the general variant takes a window at ANY alignment (a view one value into a tensor): two scalar loads
+      static_for<E>([&](auto q) { wv[q] = cx<T>{(win + 2 * TP * q)[2 * (unsigned)tid], (win + 2 * TP * q + 1)[2 * (unsigned)tid]}; });
     }
     load_order_fence();
   }
@@ -1020,9 +1036,11 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     if constexpr (kAdj) tb = reinterpret_cast<const V4 *>(twr)[(unsigned)tid];
     else twk0 = reinterpret_cast<const cx<T> *>(twr)[(unsigned)tid];
     static_assert(WIN <= 1 || PDSP_TABLES_FIRST, "fused windows are written for the tables-first order");
-    if constexpr (HAS_WIN) {
+    if constexpr (HAS_WIN && FAST) {
       const cx<T> *const w2 = reinterpret_cast<const cx<T> *>(win);
       static_for<E>([&](auto q) { x[q] = x[q] * (w2 + TP * q)[(unsigned)tid]; });
+    } else if constexpr (HAS_WIN) {
+      static_for<E>([&](auto q) { x[q] = x[q] * cx<T>{(win + 2 * TP * q)[2 * (unsigned)tid], (win + 2 * TP * q + 1)[2 * (unsigned)tid]}; });
     }
   }
 #ifdef PDSP_STAMPS
@@ -2052,7 +2070,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   const cx<T> umid = a[E / 2];  // thread 0: U[2048] = Z[4096], the bin that pairs with itself
   __syncthreads();
 
-  T *const arow = amp + (size_t)row * (size_t)amp_pitch;  // M + 1 = packed rows; a larger pitch aligns every row
+  T *const arow = amp + (size_t)row * (size_t)(amp_pitch < 0 ? -amp_pitch : amp_pitch);  // M + 1 = packed rows
   const bool store_amp = !PEAK || amp != nullptr;
   PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);
@@ -2112,7 +2130,10 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     if (store_amp) {
       if constexpr (PDSP_DIF_BUFFER && sizeof(T) == 4) {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mae, mao}), ws, vo_lo, 2048 * q, 2 /* nt */);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mbo, mbe}), ws, vo_hi, 2048 * (7 - q), 2);
+        if (amp_pitch < 0)  // EXPERIMENT: the mirrored pairs (4 bytes off an 8-byte boundary) as PLAIN stores, L2 merges them
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mbo, mbe}), ws, vo_hi, 2048 * (7 - q), 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mbo, mbe}), ws, vo_hi, 2048 * (7 - q), 2);
       } else {
         __builtin_nontemporal_store(V2{mae, mao}, reinterpret_cast<V2 *>(arow + (unsigned)(2 * k)));
         __builtin_nontemporal_store(V2{mbo, mbe}, reinterpret_cast<V2 *>(arow + (unsigned)(M - 1 - 2 * k)));

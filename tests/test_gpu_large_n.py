@@ -267,3 +267,63 @@ def test_long_frame_spectrum_on_tile_passes_vs_fourstep_vs_oracle(pdsp, oracle_m
     xs[:, n - 1000:] = 0
     wamp, _, _ = oracle_mod.Plan(n).spectrum_batch(xs, window=oracle_mod.create_window("hann", n).astype(np.float32))
     assert rel_err(amp.cpu().numpy(), wamp) <= 1e-5
+
+
+def test_partially_overlapping_output_planes_at_2p19(pdsp, oracle_mod):
+    """the three-pass tile path used the output planes as its first scratch pair unless the POINTERS were
+    equal; an output that starts one row into the input buffer overlaps it without being equal, and pass 1 then
+    overwrote input other workgroups had not read yet.  Byte-range test now (planes_overlap)."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    n, batch = 1 << 19, 3
+    rng = np.random.default_rng(19)
+    re = rng.standard_normal((batch, n)).astype(np.float32)
+    im = rng.standard_normal((batch, n)).astype(np.float32)
+    wre, wim = oracle_mod.Plan(n).forward_complex(re, im)
+    want = wre + 1j * wim
+    plan = BatchedFft(n, "cuda:0")
+    big_re = torch.zeros((batch + 1, n), device="cuda")
+    big_im = torch.zeros((batch + 1, n), device="cuda")
+    big_re[:batch].copy_(torch.from_numpy(re))
+    big_im[:batch].copy_(torch.from_numpy(im))
+    # input = rows 0 .. batch-1, output = rows 1 .. batch of the same buffers: shifted by one row
+    plan.forward(big_re[:batch], big_im[:batch], out=(big_re[1:], big_im[1:]))
+    torch.cuda.synchronize()
+    got = big_re[1:].cpu().numpy().astype(np.float64) + 1j * big_im[1:].cpu().numpy()
+    assert rel_err(got, want) <= 1e-5
+    # the same with only ONE plane overlapping (real output over the imaginary input, shifted)
+    big = torch.zeros((batch + 1, n), device="cuda")
+    big[:batch].copy_(torch.from_numpy(im))
+    dre = torch.from_numpy(re).cuda()
+    oim = torch.empty((batch, n), device="cuda")
+    plan.forward(dre, big[:batch], out=(big[1:], oim))
+    torch.cuda.synchronize()
+    got = big[1:].cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy()
+    assert rel_err(got, want) <= 1e-5
+
+
+def test_scratch_planes_go_back_to_the_device_with_the_plan(pdsp):
+    """the multi-pass paths' scratch planes come from a pool of the engine's own with an unlimited
+    release threshold; they used to stay with the process until pdsp_plan_cache_clear().  Destroying the plan
+    (BatchedFft.close / collection) now trims the pool."""
+    import gc
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    pdsp.lib.pdsp_plan_cache_clear()
+    free0, _ = torch.cuda.mem_get_info()
+    n, batch = 1 << 22, 32                      # 512 MiB per plane: ~2 GiB of scratch on the three-pass path
+    plan = BatchedFft(n, "cuda:0")
+    re = torch.randn((batch, n), device="cuda")
+    im = torch.randn((batch, n), device="cuda")
+    plan.forward(re, im, out=(re, im))         # in place: both scratch pairs come from the pool
+    torch.cuda.synchronize()
+    del re, im
+    torch.cuda.empty_cache()
+    # (what the pool holds at this point is the runtime's business: on ROCm 7.2 hipMemGetInfo already reports the
+    # freed planes as free here; the contract checked is the one after the plan is gone)
+    plan.close()
+    gc.collect()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (256 << 20), f"scratch planes still pinned after the plan is gone: {(free0 - free1) >> 20} MiB"

@@ -35,14 +35,14 @@ def launch(pitch, amp):
 
 if "--pmc" in sys.argv:
     pitch = int(sys.argv[sys.argv.index("--pmc") + 1])
-    amp = torch.empty((chunk, max(pitch, bins)), dtype=torch.float32, device=dev)
+    amp = torch.empty((chunk, max(abs(pitch), bins)), dtype=torch.float32, device=dev)
     for _ in range(6):
         launch(pitch, amp)
     torch.cuda.synchronize()
     sys.exit(0)
 
-pitches = [0, 8200, 8208, 8224]
-amps = {p: torch.empty((chunk, max(p, bins)), dtype=torch.float32, device=dev) for p in pitches}
+pitches = [0, 8224, -8193, -8224]  # negative: the same pitch, mirrored pairs as plain stores
+amps = {p: torch.empty((chunk, max(abs(p), bins)), dtype=torch.float32, device=dev) for p in pitches}
 # parity of the pitched rows against the packed ones, bit for bit (same kernel, same arithmetic)
 launch(0, amps[0])
 for p in pitches[1:]:
@@ -75,5 +75,5 @@ for p in pitches:
     med = v[len(v) // 2]
     pw = [a for a, _ in power[p] if a]
     ck = [b for _, b in power[p] if b]
-    print(f"pitch {p or bins:5d} floats: med {med:.4f} ms = {nbytes / med / 1e6:6.0f} GB/s ({nbytes / med / 1e6 / 80:.1f} %)   min {v[0]:.4f} ms"
+    print(f"pitch {p or bins:6d} floats: med {med:.4f} ms = {nbytes / med / 1e6:6.0f} GB/s ({nbytes / med / 1e6 / 80:.1f} %)   min {v[0]:.4f} ms"
           f"   power {np.median(pw) if pw else float('nan'):.0f} W  sclk {np.median(ck) if ck else float('nan'):.0f} MHz", flush=True)

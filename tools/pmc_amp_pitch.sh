@@ -4,7 +4,7 @@
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/${1:-gpurun_out/pmc_pitch}
 mkdir -p "$OUT"; cd /tmp && export TMPDIR=/tmp
-for P in 0 8208 8224; do
+for P in 0 8224 -8193 -8224; do
   for C in WRITE_SIZE FETCH_SIZE; do
     rocprofv3 --pmc $C --output-format csv -d "$OUT/p${P}_$C" -- python3 $REPO/tools/ab_amp_pitch.py --pmc $P > "$OUT/p${P}_$C.log" 2>&1
   done
