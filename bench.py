@@ -852,6 +852,27 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     return 0
 
 
+def close_orphan_rccl_groups(exc) -> int:
+    """A bring-up that fails INSIDE dist.new_group (eager connect refused: two ranks on one card, a sick fabric) leaves
+    a half-made ProcessGroupNCCL that no caller holds a handle to; its destructor then warns "destroy_process_group()
+    was not called" at exit and may leak the communicator.  The object is still a local of the frames the exception
+    passed through: find it there and abort it.  Returns how many were closed."""
+    import torch.distributed as dist
+    cls = getattr(dist, "ProcessGroupNCCL", None)
+    closed, seen, tb = 0, set(), exc.__traceback__
+    while tb is not None and cls is not None:
+        for v in list(tb.tb_frame.f_locals.values()):
+            if isinstance(v, cls) and id(v) not in seen:
+                seen.add(id(v))
+                try:
+                    v.abort()
+                    closed += 1
+                except Exception:  # noqa: BLE001
+                    pass
+        tb = tb.tb_next
+    return closed
+
+
 def exchange_leg(args, world: int, rank: int, dev, plan, re, ore, oim, per_gpu: int, out, barrier) -> dict:
     """The path's one exchange step (north_star: "RCCL over xGMI only for the final gather"), after the
     timed region: the all-gather of (i) one 16-byte SpectrumPeak record per frame (fused findPeak over the rows'
@@ -872,18 +893,26 @@ def exchange_leg(args, world: int, rank: int, dev, plan, re, ore, oim, per_gpu: 
     def timed_gather(tensors, rows_per_rank, check=False):
         gather_rows(tensors[0][:8], 8 * world, xgrp, force_collective=True)  # communicator warm-up, untimed
         barrier()
-        g0 = time.perf_counter()
-        outs = [gather_rows(t, rows_per_rank * world, xgrp, force_collective=True) for t in tensors]
-        if dev is not None:
-            torch.cuda.synchronize(dev)
-        sec = max_over_ranks(time.perf_counter() - g0)
+        # one plane at a time: a gathered plane (world x 2 GiB at configs[4]) is checked and dropped before the next
+        # is received, so the leg never holds more than one of them
+        sec, rows, intact = 0.0, 0, True
+        r0 = rank * rows_per_rank
+        for t in tensors:
+            g0 = time.perf_counter()
+            full = gather_rows(t, rows_per_rank * world, xgrp, force_collective=True)
+            if dev is not None:
+                torch.cuda.synchronize(dev)
+            sec += time.perf_counter() - g0
+            rows = int(full.shape[0])
+            if check:  # this rank's own rows came back where they belong, bit for bit
+                intact = intact and bool(torch.equal(full[r0:r0 + rows_per_rank], t))
+            del full
+        sec = max_over_ranks(sec)
         nbytes = sum(t.numel() * t.element_size() for t in tensors)
         res = {"ms": sec * 1e3, "bytes_per_rank": nbytes, "GBps_in_per_gpu": nbytes * (world - 1) / sec / 1e9,
-               "rows_gathered": int(outs[0].shape[0])}
-        if check:  # this rank's own rows came back where they belong, bit for bit
-            r0 = rank * rows_per_rank
-            res["own_rows_intact"] = bool(all(torch.equal(o[r0:r0 + rows_per_rank], t) for o, t in zip(outs, tensors)))
-        del outs
+               "rows_gathered": rows}
+        if check:
+            res["own_rows_intact"] = intact
         return res
     try:  # a failed exchange is reported, not fatal
         pk_i, pk_f, pk_a, pk_p, _, _ = plan.spectrum_peaks(re, "hann", "one", 48000.0)
@@ -907,6 +936,8 @@ def exchange_leg(args, world: int, rank: int, dev, plan, re, ore, oim, per_gpu: 
                 torch.cuda.synchronize(dev)
             except Exception as exc:  # noqa: BLE001
                 up, why = 0.0, f"{type(exc).__name__}: {exc}"
+                with dog.lock:
+                    gather["orphan_groups_closed"] = close_orphan_rccl_groups(exc)
             if max_over_ranks(1.0 - up) > 0.0:
                 raise RuntimeError("RCCL group did not come up on every rank" + (f" (this rank: {why})" if why else ""))
             with dog.lock:

@@ -107,25 +107,39 @@ __device__ __forceinline__ cx<T> conj(const cx<T> a) {
   return cx<T>{a.x, -a.y};
 }
 // a + (-i)*b = (a.re + b.im, a.im - b.re)  and  a + i*b = (a.re - b.im, a.im + b.re).
-// For f32 the half swap and the sign ride on the op_sel / neg modifiers of ONE v_pk_add_f32; hipcc does
-// not find that form by itself (it materialises (-i)*b with a v_xor + v_mov first: 21 % of the N=16384
-// spectrum kernel's vector instructions were such pairs), hence the inline asm.
+// ONE packed instruction each.  hipcc does not fold a per-half negation into v_pk_add_f32's neg_lo / neg_hi (written as
+// plain arithmetic it materialises (-i)*b with a v_xor + v_mov first: 21 % of the N=16384 spectrum kernel's vector
+// instructions were such pairs in round 1), so rounds 1-2 spelled the add in inline asm with op_sel / neg modifiers.
+// Round 3: hipcc DOES fold the half swap of a v_pk_fma_f32 operand into op_sel, and a multiply by (1, -1) is exact, so
+// fma(b.yx, (1, -1), a) is the same value bit for bit, one v_pk_fma_f32 with the constant in an SGPR pair -- and no
+// inline asm: every asm statement is an opaque instruction that hipcc pads with an s_nop against its neighbours
+// (68 of the N=4096 complex kernel's 673 instructions were such pads) and cannot schedule around.
+#ifndef PDSP_CMUL_ONE_ASM
+#define PDSP_CMUL_ONE_ASM 1
+#endif
+#ifndef PDSP_ROT_ASM
+#define PDSP_ROT_ASM 0  /* 1: rounds 1-2's inline-asm v_pk_add_f32 forms (A/B builds) */
+#endif
 template <typename T>
 __device__ __forceinline__ cx<T> add_mul_neg_i(const cx<T> a, const cx<T> b) {
-  if constexpr (std::is_same_v<T, float>) {
+  if constexpr (std::is_same_v<T, float> && PDSP_ROT_ASM) {
     cx<float> r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
+  } else if constexpr (std::is_same_v<T, float>) {
+    return __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), cx<float>{1.0f, -1.0f}, a);
   } else {
     return cx<T>{a.x + b.y, a.y - b.x};
   }
 }
 template <typename T>
 __device__ __forceinline__ cx<T> add_mul_pos_i(const cx<T> a, const cx<T> b) {
-  if constexpr (std::is_same_v<T, float>) {
+  if constexpr (std::is_same_v<T, float> && PDSP_ROT_ASM) {
     cx<float> r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
+  } else if constexpr (std::is_same_v<T, float>) {
+    return __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), cx<float>{-1.0f, 1.0f}, a);
   } else {
     return cx<T>{a.x - b.y, a.y + b.x};
   }
@@ -135,10 +149,21 @@ __device__ __forceinline__ cx<T> add_mul_pos_i(const cx<T> a, const cx<T> b) {
 template <typename T>
 __device__ __forceinline__ cx<T> cmul(const cx<T> a, const cx<T> w) {
   if constexpr (std::is_same_v<T, float>) {
+#if PDSP_CMUL_ONE_ASM
+    // both instructions in ONE statement (the product accumulates in the result register): half the asm boundaries
+    // for hipcc to pad, one register less
+    cx<float> r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r)
+        : "v"(a), "v"(w));
+    return r;
+#else
     cx<float> t, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
+#endif
   } else {
     return a.xx * w + a.yy * cx<T>{-w.y, w.x};
   }
@@ -1043,6 +1068,15 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       static_for<E>([&](auto q) { x[q] = x[q] * cx<T>{(win + 2 * TP * q)[2 * (unsigned)tid], (win + 2 * TP * q + 1)[2 * (unsigned)tid]}; });
     }
   }
+  // The adjacent-bin split takes a frame PRE-SCALED by g = s_mid / 2 (a power of two: exact) and multiplies by
+  // nothing: the fused windows carry g in their coefficients (WinFused); the rect and table variants multiply here --
+  // one packed multiply per pair of samples instead of four per pair of bins.  edge = s_edge / s_mid fixes up DC and
+  // Nyquist, which are not doubled.
+  const T edge = WIN >= 2 ? T(wf.edge_ratio) : s_edge / s_mid;
+  if constexpr (kAdj && WIN <= 1) {
+    const T g = T(0.5) * s_mid;
+    static_for<E>([&](auto q) { x[q] = x[q] * g; });
+  }
 #ifdef PDSP_STAMPS
   pin_regs<T, E>(x);  // land the frame + window here
 #endif
@@ -1072,21 +1106,14 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       const cx<T> z0 = lrow[lds_pad(k0)], z1 = lrow[lds_pad(k0) + 1];          // k0 % 16 <= 14: same block of 16
       const cx<T> zp0 = lrow[lds_pad((M - k0) & (M - 1))], zp1 = lrow[lds_pad(M - k0 - 1)];
       const cx<T> w0 = mul_w32<T, 2 * q>(tw0), w1 = mul_w32<T, 2 * q>(tw1);
-      cx<T> e0, p0, e1, p1;
-      if constexpr (WIN >= 2) {
-        // the frame came in pre-scaled by s_mid / 2 (folded into the fused window's coefficients): no
-        // multiplies here; DC and Nyquist (k0 = 0: not doubled) are fixed up on xa0 / xb0 below
-        e0 = z0 + conj(zp0), p0 = cmul(z0 - conj(zp0), w0);
-        e1 = z1 + conj(zp1), p1 = cmul(z1 - conj(zp1), w1);
-      } else {
-        const T h0 = T(0.5) * ((k0 == 0) ? s_edge : s_mid), h1 = T(0.5) * s_mid;
-        e0 = (z0 + conj(zp0)) * h0, p0 = cmul(z0 - conj(zp0), w0) * h0;
-        e1 = (z1 + conj(zp1)) * h1, p1 = cmul(z1 - conj(zp1), w1) * h1;
-      }
+      // the frame came in pre-scaled by s_mid / 2: no multiplies here; DC and Nyquist (k0 = 0: not doubled) are
+      // fixed up on xa0 / xb0 below
+      const cx<T> e0 = z0 + conj(zp0), p0 = cmul(z0 - conj(zp0), w0);
+      const cx<T> e1 = z1 + conj(zp1), p1 = cmul(z1 - conj(zp1), w1);
       cx<T> xa0 = add_mul_neg_i(e0, p0), xb0 = conj(add_mul_pos_i(e0, p0));        // X[k0], X[M - k0]
       const cx<T> xa1 = add_mul_neg_i(e1, p1), xb1 = conj(add_mul_pos_i(e1, p1));  // X[k0 + 1], X[M - k0 - 1]
-      if constexpr (WIN >= 2 && q == 0) {
-        const T r = tid == 0 ? T(wf.edge_ratio) : T(1);  // k0 = 0 lives in thread 0's first pair
+      if constexpr (q == 0) {
+        const T r = tid == 0 ? edge : T(1);  // k0 = 0 lives in thread 0's first pair
         xa0 = xa0 * r;
         xb0 = xb0 * r;
       }
@@ -1108,7 +1135,7 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
       }
     });
     if (tid == 0) {  // the middle bin M/2 pairs with itself: X[M/2] = conj(Z[M/2]) scaled
-      const cx<T> xm = conj(lrow[lds_pad(M / 2)]) * (WIN >= 2 ? T(2) : s_mid);  // pre-scaled frames carry s_mid / 2
+      const cx<T> xm = conj(lrow[lds_pad(M / 2)]) * T(2);  // the pre-scaled frame carries s_mid / 2; one value, not a sum
       const T mm = mag(xm);
       if constexpr (PEAK) best.consider(mm, M / 2, xm);
       if (store_amp) st_rowtail(mm, arow + (unsigned)(M / 2));
@@ -2027,10 +2054,21 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     });
   }
   load_order_fence();
-  if constexpr (HAS_WIN) {
+  // Every variant hands the sub-transforms a frame PRE-SCALED by g = s_mid / 2 (a power of two: exact), so that the
+  // Hermitian split multiplies by nothing: the fused windows carry g in their coefficients (WinFused), the table
+  // and rect variants multiply here (one packed multiply per pair of samples, against four per bin pair in the
+  // split).  DC and Nyquist, which are not doubled, get edge = s_edge / s_mid on their two values.
+  const T edge = WIN >= 2 ? T(wf.edge_ratio) : s_edge / s_mid;
+  if constexpr (WIN <= 1) {
+    const T g = T(0.5) * s_mid;
     static_for<E>([&](auto q) {
-      a[q] = a[q] * wlo[q];
-      b[q] = b[q] * whi[q];
+      if constexpr (HAS_WIN) {
+        a[q] = a[q] * (wlo[q] * g);
+        b[q] = b[q] * (whi[q] * g);
+      } else {
+        a[q] = a[q] * g;
+        b[q] = b[q] * g;
+      }
     });
   }
   if constexpr (WIN >= 2) {
@@ -2094,24 +2132,16 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     const cx<T> zpo = lds[Q + (Q - 1) - TP * q - tid];
     const cx<T> we = mul_w32<T, q>(wc0);  // W_16384^(2k)
     const cx<T> wo = mul_w32<T, q>(ws1);  // W_16384^(2k+1)
-    cx<T> ee, pe, eo, po;
-    if constexpr (WIN >= 2) {
-      // the frame came in pre-scaled by s_mid / 2 (folded into the fused window's coefficients): no
-      // multiplies here; DC and Nyquist (k = 0: not doubled) are fixed up on the two magnitudes below
-      ee = ze + conj(zpe), pe = cmul(ze - conj(zpe), we);
-      eo = zo + conj(zpo), po = cmul(zo - conj(zpo), wo);
-    } else {
-      // the amplitude scale rides on the 1/2 of the split (DC and Nyquist, k = 0, are not doubled)
-      const T he = T(0.5) * ((k == 0) ? s_edge : s_mid), ho = T(0.5) * s_mid;
-      ee = (ze + conj(zpe)) * he, pe = cmul(ze - conj(zpe), we) * he;
-      eo = (zo + conj(zpo)) * ho, po = cmul(zo - conj(zpo), wo) * ho;
-    }
+    // the frame came in pre-scaled by s_mid / 2: no multiplies here; DC and Nyquist (k = 0: not doubled) are fixed
+    // up on their two values below
+    const cx<T> ee = ze + conj(zpe), pe = cmul(ze - conj(zpe), we);
+    const cx<T> eo = zo + conj(zpo), po = cmul(zo - conj(zpo), wo);
     cx<T> xae = add_mul_neg_i(ee, pe);        // scaled X[2k]
     cx<T> xbe = conj(add_mul_pos_i(ee, pe));  // scaled X[8192 - 2k]
     const cx<T> xao = add_mul_neg_i(eo, po);        // scaled X[2k + 1]
     const cx<T> xbo = conj(add_mul_pos_i(eo, po));  // scaled X[8191 - 2k]
-    if constexpr (WIN >= 2 && q == 0) {
-      const T r = tid == 0 ? T(wf.edge_ratio) : T(1);  // k = 0 lives in thread 0's first pair
+    if constexpr (q == 0) {
+      const T r = tid == 0 ? edge : T(1);  // k = 0 lives in thread 0's first pair
       xae = xae * r;
       xbe = xbe * r;
     }
@@ -2143,7 +2173,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   // the middle bin 4096 = 2*2048 pairs with itself: X[4096] = conj(Z[4096]) = conj(U[2048])
   if (tid == 0) {
     const cx<T> xm = conj(umid);
-    const T mm = mag(xm) * (WIN >= 2 ? T(2) : s_mid);  // pre-scaled frames carry s_mid / 2 already
+    const T mm = mag(xm) * T(2);  // the pre-scaled frame carries s_mid / 2; this bin is one value, not a sum of two
     if constexpr (PEAK) best.consider(mm, H, xm);
     if (store_amp) st_rowtail(mm, arow + (unsigned)H);
   }

@@ -25,7 +25,7 @@ def _run(argv, timeout=240, env=None):
                           env=env or _env(), cwd=ROOT)
 
 
-@pytest.mark.parametrize("gpus,batch", [(2, 65536), (3, 7)])
+@pytest.mark.parametrize("gpus,batch", [(2, 65536), (3, 7), (8, 4096)])
 def test_gpus_flag_launches_child_ranks(gpus, batch):
     p = _run(["--gpus", str(gpus), "--dry-run", "--batch", str(batch)])
     assert p.returncode == 0, p.stderr[-2000:]
