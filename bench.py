@@ -278,7 +278,7 @@ def stream_throughput(args, dev) -> int:
     return 0
 
 
-def parity_vs_oracle(kind: str, inputs, outputs, n: int, window: str | None = None):
+def parity_vs_oracle(kind: str, inputs, outputs, n: int, window: str | None = None, tol: float = 1e-5):
     """Outside the timed region: rows of the very buffers the timed steps wrote, checked against the
     CPU oracle (the checker, never the thing measured).  Stated fp32 tolerance of the path:
     per row max|got - want| / max|want| <= 1e-5, against the f64 restatement of src/core/fft.ts fed the
@@ -297,8 +297,8 @@ def parity_vs_oracle(kind: str, inputs, outputs, n: int, window: str | None = No
         wre, wim = plan.forward_complex(re, im) if kind == "complex" else plan.forward(re)
         want = wre + 1j * wim
         err = np.abs((gre + 1j * gim) - want).max(axis=1) / np.abs(want).max(axis=1)
-    return {"rows": int(err.shape[0]), "max_rel_err": float(err.max()), "tolerance": 1e-5,
-            "ok": bool(err.max() <= 1e-5), "against": "oracle/pdsp_oracle.c (f64), rows drawn with seed 1337"}
+    return {"rows": int(err.shape[0]), "max_rel_err": float(err.max()), "tolerance": tol,
+            "ok": bool(err.max() <= tol), "against": "oracle/pdsp_oracle.c (f64), rows drawn with seed 1337"}
 
 
 def read_clocks(dev=None, ours_only=False):
@@ -461,7 +461,7 @@ def parse_args(argv):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024", "stream"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft4096_f64", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024", "stream"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None, help="spectrum256 only: another frame size (development sweeps)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
@@ -609,18 +609,24 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     # (pragma-dsp_amd/shard.py); no collective on the data path
     row0, row1 = my_rows(per_gpu * world, rank, world)
     assert row1 - row0 == per_gpu
-    plan = BatchedFft(n, dev)
+    f64 = args.workload == "fft4096_f64"  # the headline shape in the reference's own precision (fft.ts:1-14)
+    plan = BatchedFft(n, dev, dtype=torch.float64 if f64 else torch.float32)
     stream = torch.cuda.current_stream(dev)
     parity_kind, amp = None, None
 
-    if args.workload in ("fft4096", "fft16k"):
+    if args.workload in ("fft4096", "fft16k", "fft4096_f64"):
         re, im = synth_batch(per_gpu, n, dev, seed=1337 + rank)
+        if f64:
+            re, im = re.double(), im.double()
         ore, oim = torch.empty_like(re), torch.empty_like(im)
         launches_per_step = 1
-        bytes_per_launch = 16 * per_gpu * n  # 8 B read + 8 B written per sample
+        bytes_per_launch = (32 if f64 else 16) * per_gpu * n  # 8 B read + 8 B written per f32 sample
         parity_kind = "complex"
         kernel_name, kernel_label = "fft_stockham_kernel<float, 12, pdsp::LoadComplex", \
             "fft_stockham_kernel<float, 12, LoadComplex, StoreComplex>"
+        if f64:
+            kernel_name, kernel_label = "fft_stockham_kernel<double, 12, pdsp::LoadComplex", \
+                "fft_stockham_kernel<double, 12, LoadComplex, StoreComplex>"
         if args.workload == "fft16k":
             kernel_name, kernel_label = "fft_split4_kernel<float, 12, pdsp::LoadComplex", \
                 "fft_split4_kernel<float, 12, LoadComplex, StoreComplex>"
@@ -724,7 +730,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     # context for the roofline fraction (outside the timed region): the rate at which this box, with
     # these very buffers, copies the input planes to the output planes (torch's device copy kernel)
     copy_gbps, copy_clocks = None, None
-    if args.workload in ("fft4096", "fft16k") and rank == 0 and world == 1:
+    if args.workload in ("fft4096", "fft16k", "fft4096_f64") and rank == 0 and world == 1:
         for _ in range(3):
             ore.copy_(re)
             oim.copy_(im)
@@ -765,9 +771,10 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64" if f64 else "f32",
             "data": "synthetic",
             "config": {"workload": {"fft4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex (configs[2])",
+                                    "fft4096_f64": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forwardComplex f64 planar complex (configs[2]'s shape in the reference's precision)",
                                     "real4096": f"N=4096 batch={per_gpu}/GPU Radix2Fft.forward fp32 real input",
                                     "fft16k": f"N=16384 batch={per_gpu}/GPU Radix2Fft.forwardComplex fp32 planar complex",
                                     "spectrum256": f"N={n} batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude",
@@ -819,7 +826,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                 sel = torch.randperm(per_gpu, generator=g)[:256].sort().values.to(dev)
                 ins = (re[sel].cpu().numpy(), im[sel].cpu().numpy() if im is not None else None)
                 outs = (ore[sel].cpu().numpy().astype(np.float64), oim[sel].cpu().numpy().astype(np.float64))
-                out["parity"] = parity_vs_oracle(parity_kind, ins, outs, n)
+                out["parity"] = parity_vs_oracle(parity_kind, ins, outs, n, tol=1e-12 if f64 else 1e-5)
             elif parity_kind == "spectrum":
                 sel = torch.randperm(re.shape[0], generator=g)[:64 if n > 4096 else 256].sort().values.to(dev)
                 out["parity"] = parity_vs_oracle("spectrum", (re[sel].cpu().numpy(),),
@@ -830,7 +837,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         if world == 1 and not args.no_cpu_baseline:
             rows = 2048
             sel = torch.cat([torch.arange(0, rows // 2), torch.arange(per_gpu // 2, per_gpu // 2 + rows // 2)]) \
-                if args.workload in ("fft4096", "real4096") else torch.arange(0, min(rows, re.shape[0]))
+                if args.workload in ("fft4096", "real4096", "fft4096_f64") else torch.arange(0, min(rows, re.shape[0]))
             hre = re[sel.to(dev)].cpu().numpy().astype(np.float64)
             him = im[sel.to(dev)].cpu().numpy().astype(np.float64) if im is not None else None
             out["cpu_baseline"] = cpu_baseline(hre, him, n, args.cpu_seconds)

@@ -48,12 +48,6 @@ PDSP_API int pdsp_set_twopass(int enabled);
  * within rounding.  f32 real rows always take the complex kernels (no gain measured: DESIGN 4.1c). */
 PDSP_API int pdsp_set_real_packed(int enabled);
 
-/* EXPERIMENT: row pitch, in values, of the one-sided amplitude rows that
- * spectrum_dif16k_kernel writes (whole N = 16384 f32 frames): 0 (default) = packed rows of N/2 + 1 = 8193 values,
- * which never start on a cache line; e.g. 8224 starts every row on a 128-byte line.  The caller's amp_out must
- * then hold batch * pitch values.  Only that kernel honours it. */
-PDSP_API int pdsp_set_amp_pitch(int values);
-
 #ifdef __cplusplus
 }
 #endif

@@ -74,7 +74,6 @@ def _load() -> C.CDLL:
         "pdsp_set_fused_window": ([i32], i32),
         "pdsp_set_twopass": ([i32], i32),
         "pdsp_set_real_packed": ([i32], i32),
-        "pdsp_set_amp_pitch": ([i32], i32),
         "pdsp_plan_window_f32": ([vp, i32, C.POINTER(vp)], i32),
         "pdsp_plan_window_f64": ([vp, i32, C.POINTER(vp)], i32),
         "pdsp_is_pow2": ([ll], i32),

@@ -32,7 +32,6 @@ int g_fused_window = 1;
 int g_twopass = 1;       // pdsp_set_twopass: 2^15 <= N <= 2^18 f32 transforms in two passes (balanced factors)  // pdsp_set_fused_window: plan-owned cosine-sum windows evaluated in the kernel
 int g_split8k_f32 = 0;  // f32 N = 8192 rows on fft_split2_kernel too (A/B: pdsp_set_split16k bit 1)
 int g_staged_small = 1;
-int g_amp_pitch = 0;    // pdsp_set_amp_pitch (experiment): row pitch, in values, of spectrum_dif16k_kernel's amplitude rows
 int g_real_packed = 1;  // pdsp_set_real_packed: Radix2Fft.forward rows of 512 <= N <= 16384 on fft_real_kernel
 
 int fail(int code, const char *fmt, ...) {
@@ -1504,8 +1503,7 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
         const int mode = wmode;
 #define PDSP_DIF(W, P)                                                                                              \
   hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames,  \
-                     window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch,        \
-                     (long long)((g_amp_pitch < 0 ? -1 : 1) * (std::abs(g_amp_pitch) > bins ? std::abs(g_amp_pitch) : bins)))
+                     window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch)
 #define PDSP_DIF_P(W)    \
   do {                   \
     if (pk) PDSP_DIF(W, true); \
@@ -1748,12 +1746,6 @@ PDSP_DEFINE_PLAN_WINDOW(f64, double)
 int pdsp_set_staged_small(int enabled) {
   const int prev = g_staged_small;
   g_staged_small = enabled ? 1 : 0;
-  return prev;
-}
-
-int pdsp_set_amp_pitch(int values) {
-  const int prev = g_amp_pitch;
-  g_amp_pitch = values;  // < 0: the same pitch with the mirrored pairs as plain (not non-temporal) stores
   return prev;
 }
 

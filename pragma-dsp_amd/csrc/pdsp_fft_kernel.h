@@ -1995,8 +1995,7 @@ __global__ void __launch_bounds__(256, PDSP_DIF16K_WAVES)
 spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, const WinFused wf, const long long stride,
                        const typename vec2<T>::type *__restrict__ tw12,
                        const typename vec2<T>::type *__restrict__ twr, T *__restrict__ amp, const T s_edge,
-                       const T s_mid, PeakRec *__restrict__ peaks, const T freq_scale, const long long batch,
-                       const long long amp_pitch) {
+                       const T s_mid, PeakRec *__restrict__ peaks, const T freq_scale, const long long batch) {
   constexpr bool HAS_WIN = WIN == 1;
   static_assert(WIN <= 1 || sizeof(T) == 4, "the fused window is the f32 path's (f64 keeps the f64-built table)");
   using TR = FftTraits<12>;
@@ -2108,7 +2107,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   const cx<T> umid = a[E / 2];  // thread 0: U[2048] = Z[4096], the bin that pairs with itself
   __syncthreads();
 
-  T *const arow = amp + (size_t)row * (size_t)(amp_pitch < 0 ? -amp_pitch : amp_pitch);  // M + 1 = packed rows
+  T *const arow = amp + (size_t)row * (size_t)(M + 1);
   const bool store_amp = !PEAK || amp != nullptr;
   PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);
@@ -2160,10 +2159,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
     if (store_amp) {
       if constexpr (PDSP_DIF_BUFFER && sizeof(T) == 4) {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mae, mao}), ws, vo_lo, 2048 * q, 2 /* nt */);
-        if (amp_pitch < 0)  // EXPERIMENT: the mirrored pairs (4 bytes off an 8-byte boundary) as PLAIN stores, L2 merges them
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mbo, mbe}), ws, vo_hi, 2048 * (7 - q), 0);
-        else
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mbo, mbe}), ws, vo_hi, 2048 * (7 - q), 2);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2s, V2{mbo, mbe}), ws, vo_hi, 2048 * (7 - q), 2);
       } else {
         __builtin_nontemporal_store(V2{mae, mao}, reinterpret_cast<V2 *>(arow + (unsigned)(2 * k)));
         __builtin_nontemporal_store(V2{mbo, mbe}, reinterpret_cast<V2 *>(arow + (unsigned)(M - 1 - 2 * k)));

@@ -113,7 +113,7 @@ static int spec_main(long long frames, int rounds) {
   svs.push_back({"packed<13>", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<float, 13, true, 1, false>), dim3((frames + TR::ROWS - 1) / TR::ROWS),
                        dim3(TR::WG), 0, 0, x, win, pdsp::WinFused{nullptr, nullptr, 0.f, 0.f, 0.f, 1.f}, (long long)n, (long long)n, dtw, dtwr, amp, (float *)nullptr, 0,
-                       1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames, (long long)(n / 2 + 1)); }, {}});
+                       1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
   pdsp::WinFused wfz{nullptr, nullptr, 0.f, 0.f, 0.f, 1.f}, wfh = wfz;
   {
     const double f = 2 * M_PI / (n - 1);
@@ -136,16 +136,16 @@ static int spec_main(long long frames, int rounds) {
   }
   svs.push_back({"dif16k (x2 ld, x2 nt st)", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 1, false>), dim3(frames), dim3(256), 0, 0, x, win, wfz,
-                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames, (long long)(n / 2 + 1)); }, {}});
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
   svs.push_back({"dif16k fused hann (2-term)", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 2, false>), dim3(frames), dim3(256), 0, 0, x, win, wfh,
-                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames, (long long)(n / 2 + 1)); }, {}});
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
   svs.push_back({"dif16k fused 3-term (hann coefficients)", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 3, false>), dim3(frames), dim3(256), 0, 0, x, win, wfh,
-                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames, (long long)(n / 2 + 1)); }, {}});
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
   svs.push_back({"dif16k rect window", [&] {
     hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<float, 0, false>), dim3(frames), dim3(256), 0, 0, x, win, wfz,
-                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames, (long long)(n / 2 + 1)); }, {}});
+                       (long long)n, dtw12, dtwr, amp, 1.0f / n, 2.0f / n, (pdsp::PeakRec *)nullptr, 0.0f, frames); }, {}});
   auto run = [&] { svs[split ? 1 : 0].run(); };
   for (int i = 0; i < 10; ++i)
     for (auto &v : svs) v.run();

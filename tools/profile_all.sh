@@ -5,7 +5,7 @@
 set -o pipefail
 TAG=${1:-r01}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
-for w in fft4096 real4096 fft16k spectrum16k spectrum256 peaks16k; do
+for w in fft4096 fft4096_f64 real4096 fft16k spectrum16k spectrum256 peaks16k; do
   extra=""
   case $w in spectrum16k|peaks16k) extra="--batch 65536";; spectrum256) extra="--batch 1048576";; esac
   bash "$REPO/tools/profile_gpu.sh" "${TAG}_$w" --workload $w $extra > "$REPO/gpurun_out/prof_${TAG}_$w.log" 2>&1 || { echo "profile $w failed"; tail -5 "$REPO/gpurun_out/prof_${TAG}_$w.log"; exit 1; }
