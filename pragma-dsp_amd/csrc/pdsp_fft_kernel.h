@@ -666,6 +666,10 @@ template <typename T, int LOG2N, int LOG2E, int EE>
 __device__ __forceinline__ void fft_pass_readback(cx<T> (&x)[EE], const cx<T> *const lrow, const int tid) {
   using TR = FftTraits<LOG2N, LOG2E>;
   constexpr int E = TR::E, TP = TR::TP;
+  // (For TP <= 128 hipcc pairs these read-backs into ds_read2_b64, which the LDS serves at half ds_read_b64's rate.
+  // Keeping them apart -- round-robin opaque bases, +4 instructions -- measured +-0 on every size from 256 to 8192,
+  // C2C and fused spectrum (profiles/r03_experiments/ab_lds_read2_vs_split.log): LDS time is not what bounds these
+  // kernels, same finding as the bank-conflict experiment at lds_pad.)
   if constexpr (TP % 16 == 0) {
     const cx<T> *const rbase = lrow + lds_pad(tid);
     static_for<E>([&](auto q) { x[q] = rbase[cpad(TP * q)]; });
@@ -718,6 +722,26 @@ struct PeakBest {
   cx<T> x;  // the complex bin, so the phase is one atan2 at the very end
   __device__ __forceinline__ void consider(const T ov, const int oi, const cx<T> ox) {
     if (ov > v || (ov == v && ov > T(0) && oi < i)) {
+      v = ov;
+      i = oi;
+      x = ox;
+    }
+  }
+  // A thread that visits its OWN bins in a known index order does not need the order-independent rule: in ASCENDING
+  // order the strict '>' alone is "first wins" (an equal value at a larger index never replaces), in DESCENDING order
+  // '>=' is (an equal value at a smaller index does replace).  One compare + four selects per bin where the rule
+  // above costs four compares and their mask logic -- 32 bins per thread in the N = 16384 kernel, on a peaks-only
+  // path that is bound by instruction issue, not by HBM.  A descending run may pick up a bin of value 0; the
+  // order-independent merge that follows drops it (only values > 0 enter).  NaNs never enter, as before.
+  __device__ __forceinline__ void consider_ascending(const T ov, const int oi, const cx<T> ox) {
+    if (ov > v) {
+      v = ov;
+      i = oi;
+      x = ox;
+    }
+  }
+  __device__ __forceinline__ void consider_descending(const T ov, const int oi, const cx<T> ox) {
+    if (ov >= v) {
       v = ov;
       i = oi;
       x = ox;
@@ -1090,6 +1114,8 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   const bool store_amp = live && (!PEAK || amp != nullptr);
   T *const arow = amp + (size_t)row * (size_t)bins;
   T *const prow = (!FAST && ph) ? ph + (size_t)row * (size_t)bins : nullptr;
+  // (the ordered runs of spectrum_dif16k_kernel -- PeakBest::consider_ascending / _descending -- measured +-0 at
+  // N = 4096 and -2.3 % at N = 1024 here, where a thread owns 16 bins, not 32: the order-independent rule stays)
   PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);
   cx<T> dc_x{T(0), T(0)};
@@ -2109,7 +2135,8 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
 
   T *const arow = amp + (size_t)row * (size_t)(M + 1);
   const bool store_amp = !PEAK || amp != nullptr;
-  PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}};
+  // best: the forward bins, visited in ascending order; bestm: the mirrored bins, visited in descending order
+  PeakBest<T> best{T(0), 0, cx<T>{T(0), T(0)}}, bestm{T(0), 0, cx<T>{T(0), T(0)}};
   T dc_amp = T(0);
   cx<T> dc_x{T(0), T(0)};
   typedef T V2 __attribute__((ext_vector_type(2)));
@@ -2150,11 +2177,11 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
         dc_amp = mae;
         dc_x = xae;
       } else {
-        best.consider(mae, 2 * k, xae);
+        best.consider_ascending(mae, 2 * k, xae);
       }
-      best.consider(mao, 2 * k + 1, xao);
-      best.consider(mbo, M - 1 - 2 * k, xbo);
-      best.consider(mbe, M - 2 * k, xbe);
+      best.consider_ascending(mao, 2 * k + 1, xao);
+      bestm.consider_descending(mbe, M - 2 * k, xbe);
+      bestm.consider_descending(mbo, M - 1 - 2 * k, xbo);
     }
     if (store_amp) {
       if constexpr (PDSP_DIF_BUFFER && sizeof(T) == 4) {
@@ -2175,6 +2202,7 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
   }
 
   if constexpr (PEAK) {
+    best.consider(bestm.v, bestm.i, bestm.x);  // the thread's two runs, by the order-independent rule
     static_for<6>([&](auto sc) {
       constexpr int off = 32 >> sc;
       PeakBest<T> o;

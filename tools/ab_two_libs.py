@@ -30,6 +30,7 @@ class Lib:
         self.l.pdsp_fft_forward_real_f32.argtypes = [vp, ll, vp, vp, vp, vp]
         self.l.pdsp_spectrum_f32.argtypes = [vp, ll, vp, ll, ll, vp, i32, vp, vp, vp, vp]
         self.l.pdsp_plan_window_f32.argtypes = [vp, i32, C.POINTER(vp)]
+        self.l.pdsp_spectrum_peaks_f32.argtypes = [vp, ll, vp, ll, ll, vp, i32, C.c_double, vp, vp, vp, vp]
         self.l.pdsp_last_error.restype = C.c_char_p
         self.plans = {}
 
@@ -132,6 +133,41 @@ def spec(n, frames, rect=False):
     return make, call
 
 
+def peaks(n, frames):
+    def make():
+        x, _ = synth_batch(frames, n, dev, complex_noise=False)
+        return x, torch.empty((frames, 4), dtype=torch.int32, device=dev)
+
+    def call(L, b, _):
+        h, w = L.plan(n)
+        assert L.l.pdsp_spectrum_peaks_f32(h, frames, p(b[0]), n, n, w, 0, 48000.0, None, None, p(b[1]), sptr()) == 0
+        return (b[1],)
+    return make, call
+
+
+if "--peaks" in sys.argv:  # the fused findPeak kernels only (peaks-only output: 4 B/sample in, 16 B/frame out)
+    for n in (16384, 4096, 1024):
+        mk, cl = peaks(n, (1 << 28) // n)
+        run(f"hann peaks-only {n}x{(1 << 28) // n}", (4 * n + 16) * float((1 << 28) // n), mk, cl, 100)
+    sys.exit(0)
+if "--mid" in sys.argv:  # the sizes whose transforms have TP <= 128 threads per row
+    for n in (256, 512, 1024, 2048):
+        rows = (1 << 27) // n
+
+        def mk(n=n, rows=rows):
+            re, im = torch.randn((rows, n), device=dev), torch.randn((rows, n), device=dev)
+            return re, im, torch.empty_like(re), torch.empty_like(im)
+
+        def cl(L, b, _, n=n, rows=rows):
+            h, _w = L.plan(n)
+            assert L.l.pdsp_fft_forward_complex_f32(h, rows, p(b[0]), p(b[1]), p(b[2]), p(b[3]), sptr()) == 0
+            return b[2], b[3]
+        run(f"C2C f32 {n}x{rows}", 16.0 * rows * n, mk, cl, 60)
+    for n in (512, 1024, 2048, 4096, 8192):
+        frames = (1 << 28) // n
+        mk, cl = spec(n, frames)
+        run(f"hann spectrum {n}x{frames}", (4 * n + 4 * (n // 2 + 1)) * float(frames), mk, cl, 100)
+    sys.exit(0)
 run("configs[2] C2C f32 4096x65536", 16.0 * 65536 * 4096, c2c, c2c_call, 60)
 mk, cl = spec(16384, 16384)
 run("configs[3] hann spectrum 16384x16384", (4 * 16384 + 4 * 8193) * 16384.0, mk, cl, 100)

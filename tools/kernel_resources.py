@@ -64,7 +64,9 @@ def waves_per_simd(vgprs: int) -> int:
 def kernels(lib: str = DEFAULT_LIB):
     with tempfile.TemporaryDirectory(prefix="pdsp_kres_") as td:
         fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
-        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", lib], check=True)
+        # (an explicit output file: with the input alone llvm-objcopy rewrites the library IN PLACE)
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", lib,
+                        os.path.join(td, "copy.so")], check=True)
         subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
         notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
