@@ -1,7 +1,9 @@
-"""Radix2Fft.forward(real) rows of 512 <= N <= 16384 on fft_real_kernel -- the N/2-point packed-real transform and
-the split to X[k], X[k + N/2] (src/core/fft.ts:77-79 semantics: imaginary part taken as zero) -- against the f64
-oracle, and against the complex kernels on (x, 0) that pdsp_set_real_packed(0) (include/pdsp_hip_dev.h) routes
-the same call to.  f32 at the stated 1e-5 of the row's max, f64 at 1e-13."""
+"""Radix2Fft.forward(real) rows of 512 <= N <= 16384 (src/core/fft.ts:77-79 semantics: imaginary part taken as
+zero) against the f64 oracle.  In f64 -- the drop-in's default arithmetic -- these rows run on fft_real_kernel, the
+N/2-point packed-real transform and the split to X[k], X[k + N/2]; pdsp_set_real_packed(0)
+(include/pdsp_hip_dev.h) routes the same call to the complex kernels on (x, 0), and both forms are held to the
+oracle at 1e-13 and to each other at 1e-14.  In f32 the switch changes nothing (f32 real rows always take the complex
+kernels: DESIGN 4.1c); the f32 cases are the same checks of that path at the stated 1e-5 of the row's max."""
 import numpy as np
 import pytest
 
