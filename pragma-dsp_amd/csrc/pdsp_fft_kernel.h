@@ -368,6 +368,10 @@ __device__ __forceinline__ float mag(const cx<float> z) {
 }
 // f64 is the drop-in's default arithmetic and the reference's magnitude() is Math.hypot
 // (src/xform/fourier.ts:106): no overflow above 1e154, no underflow below 1e-162.
+// (Round 3 tried sqrt(fma(re, re, im * im)) with hypot only outside [2^-900, 2^1000]: the fast path is ~15 f64
+// instructions against hypot's ~35, 17 times per thread -- and the f64 spectrum sweep moved by +4 % at N = 1024,
+// +-1 % at 2048 ... 8192 and -6 ... -8 % at N = 128 ... 512: no gain, hypot stays.
+// profiles/r03_experiments/sweep_f64_hypot_vs_fastmag.txt)
 __device__ __forceinline__ double mag(const cx<double> z) { return hypot(z.x, z.y); }
 
 // ---- load / store policies ------------------------------------------------
