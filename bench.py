@@ -16,14 +16,24 @@ of bench/reallife/signals.ts:264-270 generalised), and the timed region is brack
 a barrier + synchronize with the MAX over ranks taken.  Rank 0 prints ONE JSON line.
 The control plane (barriers, the MAX, per-rank read-outs: host scalars) runs over gloo on loopback;
 RCCL carries the path's one exchange step, which at N > 1 follows the timed region and is
-timed on its own (`--no-gather` skips it): the all-gather over xGMI of the output slabs and of the
-16-byte-per-frame SpectrumPeak records, under a watchdog (`--gather-timeout`) -- a failed or hung
-exchange is reported in the line, the measured value stands.
+timed on its own (`--no-gather` skips it): the all-gather over xGMI of the 16-byte-per-frame SpectrumPeak
+records and of the output slabs, under a watchdog (`--gather-timeout`) -- a failed exchange is reported in
+the line (status 0), a HUNG one is abandoned: the line is printed, every rank exits 5; the measured value
+stands either way.  `--rccl-selftest` runs that leg in a world of ONE rank on one card (a real RCCL group).
+
+The default line (N = 1, no flags) also carries, outside the headline's timed region: `parity` (256 rows of the
+timed output vs the CPU oracle), `roofline.traffic` measured by two child runs under rocprofv3 --pmc,
+`also.spectrum16k` (configs[3] at its stated size: the whole 2^20-frame stream resident in HBM, its own parity and
+CPU baseline), `also.fft4096_f64` (the headline shape in the reference's own precision), `cpu_baseline` (the oracle
+and its Node restatement on one host core), `clocks` (sclk / board power under load).  A failed parity check
+makes the run exit 4.
 
 Other workloads (parity-checked elsewhere; here for DESIGN.md's numbers):
   --workload spectrum16k   configs[3]: fused Hann+FFT+one-sided amplitude, N=16384,
                            streamed in chunks of --chunk frames
   --workload real4096      Radix2Fft.forward semantics (real in, 12 B/sample)
+  --workload fft4096_f64   configs[2]'s shape in f64 (32 B/sample)
+  --workload fft16k / spectrum256 / peaks16k / single1024 (configs[1], latency) / stream (PCIe-inclusive)
 """
 from __future__ import annotations
 
