@@ -42,10 +42,11 @@ PDSP_API int pdsp_set_fused_window(int enabled);
  * A/B switch, returns the previous value. */
 PDSP_API int pdsp_set_twopass(int enabled);
 
-/* 1 (default): f64 Radix2Fft.forward rows (real input, src/core/fft.ts:77-79) of 512 <= N <= 16384 run as ONE
- * N/2-point packed-real transform per row + the split to X[k], X[k + N/2] (fft_real_kernel); 0: as the complex
- * kernel of their size on (x, 0) (fft_stockham_kernel with LoadReal; N = 16384: the four-step path).  Same results
- * within rounding.  f32 real rows always take the complex kernels (no gain measured: DESIGN 4.1c). */
+/* 1 (default): f64 Radix2Fft.forward rows (real input, src/core/fft.ts:77-79) of N = 8192, and of N = 16384 from 8
+ * rows up, run as ONE N/2-point packed-real transform per row + the split to X[k], X[k + N/2] (fft_real_kernel);
+ * 0: as the complex kernel of their size on (x, 0) (fft_stockham_kernel with LoadReal; N = 16384: the four-step
+ * path).  Same results within rounding.  Other sizes and f32 real rows always take the complex kernels
+ * (DESIGN 4.1c). */
 PDSP_API int pdsp_set_real_packed(int enabled);
 
 #ifdef __cplusplus

@@ -406,7 +406,7 @@ hipError_t launch_real(int log2m, const T *x, T *ore, T *oim, T scale, const typ
                        0, s, x, ore, oim, scale, tw, twr, batch);                                                 \
     return hipGetLastError();                                                                                     \
   }
-    PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12) PDSP_CASE(13)
+    PDSP_CASE(12) PDSP_CASE(13)
 #undef PDSP_CASE
     default:
       return hipErrorInvalidValue;
@@ -737,15 +737,19 @@ int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T 
                 pdsp_max_size((int)sizeof(T)));
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
-  // Radix2Fft.forward rows (real input) of 512 <= N <= 16384 in f64 -- the drop-in's default arithmetic: one
+  // f64 Radix2Fft.forward rows (real input; f64 is the drop-in's default arithmetic) of N = 8192 and 16384: one
   // N/2-point packed-real transform per row and the split to X[k], X[k + N/2] (fft_real_kernel) -- half the
-  // butterflies of the complex kernel on (x, 0), the same store streams, and N = 16384 stays in one pass.  Measured
-  // against the complex kernels (tools/ab_real_packed.py --f64, one process): N = 512 ... 4096 +1 ... +9 %,
-  // 8192 4.93 -> 6.57 TB/s, 16384 (was a four-step transform) 1.60 -> 5.18.  In f32 the same kernel measured
-  // 0.98 ... 1.01 of the complex kernels (both at the box's copy ceiling) and 0.74 at N = 512, so f32 real rows stay
-  // where they were and the f32 form is not built.  Rows aligned to a sample pair.
+  // butterflies of the complex kernel on (x, 0), the same store streams, and N = 16384 stays in one pass.  These are
+  // the sizes where the complex f64 kernel is short of registers (N = 8192: fft_split2_kernel's LoadReal form
+  // spilled) or does not exist (N = 16384: four-step): tools/ab_real_packed.py --f64 on two boxes, N = 8192
+  // 4.93 -> 6.57 and 3.97 -> 5.69 TB/s, N = 16384 1.60 -> 5.18 and 1.57 -> 5.07; one frame through the host drop-in
+  // (tools/ab_single_frame_latency.py) 39.7 -> 36.2 us at 8192, but 47.3 -> 50.1 us at 16384 (one 512-thread
+  // workgroup is a longer critical path than three short launches), hence the batch threshold there.  Below 8192
+  // the same kernel measured +1 ... +9 % on one box and -9 ... +2 % on another (and 3-7 % slower for one frame): not
+  // robust, not dispatched, not built.  In f32 it measured 0.98 ... 1.01 of the complex kernels: not built either.
+  // Rows aligned to a sample pair.
   if constexpr (sizeof(T) == 8) {
-    if (!im_in && g_real_packed && plan->log2n >= 9 && plan->log2n <= 14 && t.tw_half && t.twr &&
+    if (!im_in && g_real_packed && (plan->log2n == 13 || (plan->log2n == 14 && batch >= 8)) && t.tw_half && t.twr &&
         ((uintptr_t)re_in & (2 * sizeof(T) - 1)) == 0) {
       PDSP_HIP_TRY(launch_real<T>(plan->log2n - 1, re_in, re_out, im_out, scale, t.tw_half, t.twr, batch, s));
       return PDSP_OK;

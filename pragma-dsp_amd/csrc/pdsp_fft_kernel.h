@@ -1289,10 +1289,10 @@ spectrum_packed_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
 // directions, slower than the complex kernel at every size)
 //   tw = radix table of the M-point transform (Tables::tw_half), twr[k] = W_N^k (Tables::twr), scale = 1.
 // Rows must be aligned to one pair of samples.  In place row for row is fine: a workgroup loads its rows before it
-// stores.  Dispatched for f64 rows (the drop-in's default arithmetic), where it wins at every size and most where
-// the complex kernel is short of registers or LDS (N = 8192: 61.6 -> 82 % of 8 TB/s; N = 16384: one pass instead of
-// a four-step transform, 20 -> 65 %).  In f32 both forms run at the box's copy ceiling (A/B 0.98 ... 1.01), so f32
-// real rows keep the complex kernels and no f32 instance is built.
+// stores.  Dispatched for f64 rows (the drop-in's default arithmetic) of N = 8192 and N = 16384, the sizes where the
+// complex kernel is short of registers or LDS (N = 8192: 50-62 -> 71-82 % of 8 TB/s by box; N = 16384: one pass
+// instead of a four-step transform, 20 -> 63-65 %).  Below 8192 it measured +-: +1 ... +9 % on one box, -9 ... +2 %
+// on another; in f32 both forms run at the box's copy ceiling (A/B 0.98 ... 1.01): neither is built.
 template <typename T, int LOG2M>
 __global__ void __launch_bounds__(kPackedWG<LOG2M>)
 fft_real_kernel(const T *__restrict__ xin, T *__restrict__ ore, T *__restrict__ oim, const T scale,

@@ -1,9 +1,9 @@
 """Radix2Fft.forward(real) rows of 512 <= N <= 16384 (src/core/fft.ts:77-79 semantics: imaginary part taken as
-zero) against the f64 oracle.  In f64 -- the drop-in's default arithmetic -- these rows run on fft_real_kernel, the
-N/2-point packed-real transform and the split to X[k], X[k + N/2]; pdsp_set_real_packed(0)
-(include/pdsp_hip_dev.h) routes the same call to the complex kernels on (x, 0), and both forms are held to the
-oracle at 1e-13 and to each other at 1e-14.  In f32 the switch changes nothing (f32 real rows always take the complex
-kernels: DESIGN 4.1c); the f32 cases are the same checks of that path at the stated 1e-5 of the row's max."""
+zero) against the f64 oracle.  In f64 -- the drop-in's default arithmetic -- rows of N = 8192 and (from 8 rows up)
+N = 16384 run on fft_real_kernel, the N/2-point packed-real transform and the split to X[k], X[k + N/2];
+pdsp_set_real_packed(0) (include/pdsp_hip_dev.h) routes the same call to the complex kernels on (x, 0), and both
+forms are held to the oracle at 1e-13 and to each other at 1e-14.  At the other sizes and in f32 the switch changes
+nothing (those rows always take the complex kernels: DESIGN 4.1c); their cases are the same checks of that path."""
 import numpy as np
 import pytest
 
@@ -23,7 +23,7 @@ def test_real_rows_packed_vs_complex_kernel_vs_oracle(pdsp, oracle_mod, log2n, d
     dt = getattr(torch, dtype_name)
     npdt = np.float32 if dtype_name == "float32" else np.float64
     tol = TOL32 if dtype_name == "float32" else TOL64
-    batch = 37 if n <= 2048 else 7  # not a multiple of the rows per workgroup
+    batch = 37 if n <= 4096 else 9  # not a multiple of the rows per workgroup; N = 16384: >= 8 rows take the packed kernel
     rng = np.random.default_rng(7000 + log2n)
     x = rng.standard_normal((batch, n)).astype(npdt)
     idx = np.arange(n)
@@ -73,7 +73,7 @@ def test_real_rows_in_place_and_misaligned(pdsp, oracle_mod, dtype_name):
     dt = getattr(torch, dtype_name)
     npdt = np.float32 if dtype_name == "float32" else np.float64
     tol = TOL32 if dtype_name == "float32" else TOL64
-    for n, batch in ((1024, 9), (8192, 3)):
+    for n, batch in ((1024, 9), (8192, 3), (16384, 9)):
         rng = np.random.default_rng(n)
         x = rng.standard_normal((batch, n)).astype(npdt)
         want = oracle_mod.Plan(n).forward(x)

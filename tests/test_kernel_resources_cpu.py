@@ -48,8 +48,9 @@ def test_baseline_config_kernels_keep_their_occupancy(recs):
     assert k["workgroups_per_cu"] == 2
     k = find(recs, "fft_real_kernel<double, 12>")
     assert k["workgroups_per_cu"] == 2 and k["vgpr_count"] <= 256
-    # configs[1]: one N = 1024 frame through FFT.forward (f64 default: fft_real_kernel<double, 9>) and spectrum()
-    assert find(recs, "fft_real_kernel<double, 9>")["private_segment_fixed_size"] == 0
+    # configs[1]: one N = 1024 frame through FFT.forward (f64 default: the complex kernel on (x, 0))
+    assert find(recs, "fft_stockham_kernel<double, 10, LoadReal<double>, StoreComplex<double>")["private_segment_fixed_size"] == 0
+    assert find(recs, "fft_real_kernel<double, 13>")["workgroups_per_cu"] == 1
 
 
 def test_committed_table_is_this_build(recs):
