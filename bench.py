@@ -24,7 +24,8 @@ stands either way.  `--rccl-selftest` runs that leg in a world of ONE rank on on
 The default line (N = 1, no flags) also carries, outside the headline's timed region: `parity` (256 rows of the
 timed output vs the CPU oracle), `roofline.traffic` measured by two child runs under rocprofv3 --pmc,
 `also.spectrum16k` (configs[3] at its stated size: the whole 2^20-frame stream resident in HBM, its own parity and
-CPU baseline), `also.fft4096_f64` (the headline shape in the reference's own precision), `cpu_baseline` (the oracle
+CPU baseline), `also.fft4096_f64` (the headline shape in the reference's own precision), `also.single1024`
+(configs[1]: one N=1024 frame through the drop-in, microseconds, beside the Node CPU path), `cpu_baseline` (the oracle
 and its Node restatement on one host core), `clocks` (sclk / board power under load).  A failed parity check
 makes the run exit 4.
 
@@ -184,16 +185,19 @@ def traffic_measured(args, kernel_substr: str):
     return rd + wr, {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "launches_sampled": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]]}
 
 
-def single_frame_latency(args, dev) -> int:
+def single_frame_latency(args, dev, iters=None, js_iters=2000, js_sizes=None) -> dict:
     """BASELINE configs[1]: ONE N=1024 real frame, Hann window, forward FFT, magnitude.
     Latency-bound (8 KiB of traffic): reported as microseconds, not as a roofline fraction.
       dropin_spectrum_us  spectrum(x, {fftSize:1024, window:'hann'}) host f64 in -> f64 out
-                          (f64->f32, H2D, fused kernel, D2H, f32->f64, peak search)
+                          (staging, fused kernel, peak search; f64 on the device by default)
       dropin_forward_us   FFT(1024).forward(x) host f64 in -> f64 out (plan reused)
-      kernel_us           the fused kernel alone on device-resident data (HIP events)"""
+      kernel_us           the fused kernel alone on device-resident data (HIP events)
+      js_dropin_latency   the real drop-in (Node + N-API addon) in the shape of the reference's bench/run.ts, with the
+                          Node CPU restatement of the same algorithm timed beside it (tests/js/bench_latency.js)"""
     import pragma_dsp_amd as pd
     from pragma_dsp_amd.batch import BatchedFft
-    n, iters = 1024, max(args.steps, 200)
+    n = 1024
+    iters = iters or max(args.steps, 200)
     idx = np.arange(n)
     x = np.sin(2 * np.pi * 440.0 * idx / 48000.0)  # the reference's sine_440hz leakage case
     opts = {"sampleRate": 48000, "fftSize": n, "window": "hann"}
@@ -227,28 +231,27 @@ def single_frame_latency(args, dev) -> int:
     kernel_us = e0.elapsed_time(e1) * 1e3 / iters
     js = None
     if not args.no_cpu_baseline:
-        # the real drop-in (Node + N-API addon) in the shape of the reference's bench/run.ts, with the
-        # Node CPU restatement of the same algorithm timed beside it
         import shutil
         import subprocess
         node = shutil.which("node")
         if node:
             try:
-                r = subprocess.run([node, os.path.join(ROOT, "tests", "js", "bench_latency.js"), "2000"],
-                                   capture_output=True, text=True, timeout=300)
+                cmd = [node, os.path.join(ROOT, "tests", "js", "bench_latency.js"), str(js_iters)]
+                if js_sizes:
+                    cmd.append(js_sizes)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
                 js = json.loads(r.stdout) if r.returncode == 0 else {"error": r.stderr[-400:]}
             except Exception as e:
                 js = {"error": repr(e)}
-    print(json.dumps({
+    return {
         "js_dropin_latency": js,
         "metric": "single-frame latency (N=1024, Hann + FFT + magnitude)", "unit": "us", "higher_is_better": False,
-        "value": spec_med, "n_gpus": 1, "steps": iters, "warmup": 20, "dtype": "f32", "data": "synthetic",
+        "value": spec_med, "n_gpus": 1, "steps": iters, "warmup": 20, "dtype": "f64 host drop-in / f32 kernel", "data": "synthetic",
         "config": {"workload": "N=1024 single frame spectrum(), hann, one-sided (configs[1])"},
         "dropin_spectrum_us": {"median": spec_med, "min": spec_min},
         "dropin_forward_us": {"median": fwd_med, "min": fwd_min},
         "kernel_back_to_back_us": kernel_us,
-    }), flush=True)
-    return 0
+    }
 
 
 def stream_throughput(args, dev) -> int:
@@ -602,7 +605,8 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     from pragma_dsp_amd.shard import gather_rows, max_over_ranks, my_rows
 
     if args.workload == "single1024":
-        return single_frame_latency(args, dev)
+        print(json.dumps(single_frame_latency(args, dev)), flush=True)
+        return 0
     if args.workload == "stream":
         return stream_throughput(args, dev)
 
@@ -844,6 +848,12 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         if world == 1 and args.workload == "fft4096" and not args.no_also:
             out["also"] = {"spectrum16k": also_spectrum16k(args, dev, rank),
                            "fft4096_f64": also_fft4096_f64(args, dev, rank, re, im)}
+            try:  # configs[1]: one N = 1024 frame, latency (a reported extra: never fatal to the headline)
+                lat = single_frame_latency(args, dev, iters=300, js_iters=500, js_sizes="1024")
+                out["also"]["single1024"] = {k: lat[k] for k in ("config", "unit", "dropin_spectrum_us", "dropin_forward_us",
+                                                               "kernel_back_to_back_us", "js_dropin_latency")}
+            except Exception as exc:  # noqa: BLE001
+                out["also"]["single1024"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             rows = 2048
             sel = torch.cat([torch.arange(0, rows // 2), torch.arange(per_gpu // 2, per_gpu // 2 + rows // 2)]) \

@@ -10,6 +10,8 @@ const p = require(path.join(__dirname, '..', '..', 'pragma-dsp_amd', 'js'));
 const cpu = require(path.join(__dirname, '..', '..', 'oracle', 'pdsp_oracle.js'));  // CPU baseline + checker
 
 const iters = parseInt(process.argv[2] || '2000', 10);
+// optional: a comma-separated list of sizes (default: all four, plus the spectrumBatch rows)
+const only = process.argv[3] ? process.argv[3].split(',').map((v) => parseInt(v, 10)) : null;
 const now = () => Number(process.hrtime.bigint()) / 1e3;  // microseconds
 
 function stats(ts) {
@@ -32,6 +34,7 @@ const out = { node: process.version, iterations: iters, cases: [] };
 let seed = 1337;
 const rnd = () => { seed ^= seed << 13; seed ^= seed >>> 17; seed ^= seed << 5; return (seed >>> 0) / 2147483648 - 1; };
 for (const n of [1024, 2048, 4096, 16384]) {
+  if (only && only.indexOf(n) < 0) continue;
   const input = new Float64Array(n);
   for (let i = 0; i < n; i++) input[i] = rnd();
   const fft = new p.fourier.FFT(n);
@@ -73,6 +76,7 @@ for (const n of [1024, 2048, 4096, 16384]) {
 }
 // spectrumBatch: 256 frames per call
 for (const n of [1024, 4096]) {
+  if (only) continue;
   const frames = [];
   for (let b = 0; b < 256; b++) {
     const f = new Float64Array(n);
