@@ -138,3 +138,39 @@ def test_single_process_without_gpu_fails_loudly():
     assert p.returncode == 2 and "needs a GPU" in p.stderr
     p = _run(["--gpus", "2", "--steps", "1"])
     assert p.returncode == 2 and "GPU(s) visible" in p.stderr
+
+
+def test_orphan_rccl_groups_are_found_in_the_exception_frames_and_aborted(monkeypatch):
+    """A bring-up that fails inside dist.new_group leaves a half-made ProcessGroupNCCL no caller holds; bench.py finds it
+    in the frames the exception passed through and aborts it (rehearsed on the GPU box: no "destroy_process_group() was
+    not called" warning).  Here with a stand-in class, no GPU."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class FakeGroup:
+        aborted = 0
+
+        def abort(self):
+            FakeGroup.aborted += 1
+
+    monkeypatch.setattr(dist, "ProcessGroupNCCL", FakeGroup, raising=False)
+
+    def helper_that_fails():
+        backend_class = FakeGroup()  # the local torch's _new_process_group_helper holds when eager connect throws
+        other = FakeGroup()  # noqa: F841  (a second one in the same frame)
+        assert backend_class is not None
+        raise RuntimeError("NCCL error: invalid usage")
+
+    def new_group():
+        helper_that_fails()
+
+    try:
+        new_group()
+    except RuntimeError as exc:
+        assert bench.close_orphan_rccl_groups(exc) == 2
+    assert FakeGroup.aborted == 2
+    try:
+        raise ValueError("nothing to close")
+    except ValueError as exc:
+        assert bench.close_orphan_rccl_groups(exc) == 0
