@@ -2207,25 +2207,31 @@ spectrum_dif16k_kernel(const T *__restrict__ frames, const T *__restrict__ win, 
 
   if constexpr (PEAK) {
     best.consider(bestm.v, bestm.i, bestm.x);  // the thread's two runs, by the order-independent rule
-    static_for<6>([&](auto sc) {
-      constexpr int off = 32 >> sc;
-      PeakBest<T> o;
-      o.v = __shfl_xor(best.v, off, 64);
-      o.i = __shfl_xor(best.i, off, 64);
-      o.x = cx<T>{__shfl_xor(best.x.x, off, 64), __shfl_xor(best.x.y, off, 64)};
-      best.consider(o.v, o.i, o.x);
-    });
+    // Wave-wide arg-max in two scalar reductions instead of six rounds of the full rule on four shuffled values:
+    // the largest value, then the smallest index among the lanes that hold it; that lane -- unique, a bin has one
+    // owner -- hands its record to LDS itself, so the complex bin is never shuffled.  (Values are never NaN here: a
+    // NaN never enters a PeakBest.)
+    T vmax = best.v;
+    static_for<6>([&](auto sc) { vmax = fmaxf(vmax, __shfl_xor(vmax, 32 >> sc, 64)); });
+    const bool cand = vmax > T(0) && best.v == vmax;
+    int imin = cand ? best.i : 0x7fffffff;
+    static_for<6>([&](auto sc) { imin = min(imin, __shfl_xor(imin, 32 >> sc, 64)); });
     __shared__ T pk_v[4];
     __shared__ int pk_i[4];
     __shared__ cx<T> pk_x[4];
     const int wave = tid / 64;
-    if ((tid & 63) == 0) {
+    if (cand && best.i == imin) {
       pk_v[wave] = best.v;
       pk_i[wave] = best.i;
       pk_x[wave] = best.x;
+    } else if ((tid & 63) == 0 && !(vmax > T(0))) {  // nothing > 0 in this wave's bins
+      pk_v[wave] = T(0);
+      pk_i[wave] = 0;
+      pk_x[wave] = cx<T>{T(0), T(0)};
     }
     __syncthreads();
     if (tid == 0) {
+      best = PeakBest<T>{pk_v[0], pk_i[0], pk_x[0]};
       static_for<3>([&](auto wc) { best.consider(pk_v[wc + 1], pk_i[wc + 1], pk_x[wc + 1]); });
       const bool none = best.i == 0;
       const cx<T> px = none ? dc_x : best.x;

@@ -90,3 +90,27 @@ def test_real_rows_in_place_and_misaligned(pdsp, oracle_mod, dtype_name):
         ure, uim = plan.forward(view)
         torch.cuda.synchronize()
         assert rel_err(ure.cpu().numpy().astype(np.float64) + 1j * uim.cpu().numpy(), want) <= tol
+
+
+def test_host_dropin_forward_at_8192_runs_the_packed_kernel_on_pinned_memory(pdsp, oracle_mod):
+    """FFT(8192).forward(x) through the host-f64 drop-in (default f64 arithmetic): one frame, zero-copy staging -- the
+    packed kernel reads the pinned host buffer with 16-byte loads -- against the oracle at the reference's own 1e-10
+    (signals.test.ts:22-23), with `out` identity and a round trip; N = 16384 (one frame: the four-step path) beside it."""
+    for n in (8192, 16384):
+        rng = np.random.default_rng(n)
+        x = rng.standard_normal(n)
+        fft = pdsp.FFT(n)
+        out = fft.createComplexArray()
+        got = fft.forward(x, out)
+        assert got is out
+        wre, wim = oracle_mod.Plan(n).forward(x)
+        assert np.abs(out.real - wre).max() < 1e-10 and np.abs(out.imag - wim).max() < 1e-10
+        for mode in (0, 1):  # both kernels of the switch give the drop-in's answer
+            prev = pdsp.lib.pdsp_set_real_packed(mode)
+            try:
+                again = fft.forward(x)
+            finally:
+                pdsp.lib.pdsp_set_real_packed(prev)
+            assert np.abs(again.real - wre).max() < 1e-10 and np.abs(again.imag - wim).max() < 1e-10
+        back = fft.inverse(out)
+        assert np.abs(back.real - x).max() < 1e-10 and np.abs(back.imag).max() < 1e-10
