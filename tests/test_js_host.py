@@ -158,3 +158,35 @@ def test_js_dropin_parity(tmp_path, oracle_mod, reallife, manifest):
     assert rel_err(np.array(res[k + 11]), oracle_mod.magnitude(z[0], z[1])) <= 1e-6
     assert np.abs((np.array(res[k + 12]) - oracle_mod.phase(z[0], z[1]) + np.pi) % (2 * np.pi) - np.pi).max() <= 1e-5
     assert res[-1]["error"] == "FFT input length 3 != size 8"
+
+
+@needs_node
+@pytest.mark.gpu
+def test_reference_suite_in_javascript_through_the_dropin(tmp_path, reallife, v01, manifest):
+    """tests/js/reference_suite.js: every it(...) of the reference's hot-path tests (fft, spectrum, window,
+    reallife/{signals, phase, scaling, edge_cases}.test.ts), with its assertions and tolerances, run under Node
+    against pragma-dsp_amd/js -- the reference's own language on the drop-in (default f64 arithmetic).  The fixtures
+    are the reference's goldens (tests/golden/*.npz) handed over as JSON."""
+    fx = {"reallife": [], "v01": [], "windows": []}
+    for m in manifest["reallife"]:
+        re, im = reallife[m["name"] + "/fftRe"], reallife[m["name"] + "/fftIm"]
+        fx["reallife"].append({**{k: m[k] for k in ("name", "kind", "family", "n", "sampleRate", "params")},
+                               "signal": reallife[m["name"] + "/signal"].tolist(), "fftRe": re.tolist(), "fftIm": im.tolist(),
+                               "magnitude": np.hypot(re, im).tolist(), "phase": np.arctan2(im, re).tolist()})
+    for m in manifest["v01_cases"]:
+        if m["n"] > 1024:
+            continue  # the benchmark inputs: no test reads them
+        fx["v01"].append({**{k: m[k] for k in ("name", "kind", "n", "sampleRate", "meta")},
+                          "input": v01[f"case/{m['name']}/input"].tolist(), "fftRe": v01[f"case/{m['name']}/fftRe"].tolist(),
+                          "fftIm": v01[f"case/{m['name']}/fftIm"].tolist()})
+    for w in manifest["v01_windows"]:
+        fx["windows"].append({"type": w["type"], "n": w["n"], "values": v01[w["key"]].tolist()})
+    fin, fout = tmp_path / "fixtures.json", tmp_path / "results.json"
+    fin.write_text(json.dumps(fx))
+    subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "reference_suite.js"), str(fin), str(fout)], check=True, timeout=300)
+    res = json.loads(fout.read_text())
+    bad = [r for r in res if not r["ok"]]
+    assert not bad, bad[:5]
+    # 15 x 2 random cases, 1 spectrum case, 28 windows, 23 x 4 pure sines, 2 x 2 multi-tone, 1 x 2 chirp, 4 special,
+    # phase: 1 + 5 x 2 + 4, scaling: 15 x 3 + 6, edge cases: 11
+    assert len(res) == 30 + 1 + 28 + 92 + 4 + 2 + 4 + 15 + 51 + 11 == 238, len(res)
