@@ -94,3 +94,35 @@ def test_peaks_on_ragged_and_padded_frames(oracle_mod):
         assert abs(amp[b] - wamp[b, idx[b]]) <= TOL * wamp[b].max()
     with pytest.raises(Exception, match="Sample rate must be positive, got 0"):
         plan.spectrum_peaks(torch.from_numpy(x).cuda(), "hann", "one", 0)
+
+
+@pytest.mark.parametrize("n", [1024, 4096, 16384])
+def test_exact_ties_first_bin_wins_through_every_stage_of_the_fused_search(n):
+    """findPeak's "strict >, first wins" (spectrum.ts:83-98) when EVERY bin ties exactly: an impulse at sample 0 (X[k] = 1)
+    and at sample N/2 (X[k] = (-1)^k) give bit-equal amplitudes 2/N in all bins 1 .. N/2-1, so the answer must be bin 1
+    -- through the per-thread runs (ascending over the forward bins, descending over the mirrored ones at N = 16384),
+    their merge, the wave-wide reduction and the hop across waves; zeros -> bin 0 with amplitude 0; DC only -> bin 0;
+    one bin raised by one ulp-scale step wins wherever it sits (first, last, mirrored half, a wave boundary)."""
+    import torch
+    from pragma_dsp_amd.batch import BatchedFft
+    plan = BatchedFft(n, "cuda:0")
+    x = np.zeros((4, n), dtype=np.float32)
+    x[0, 0] = 1.0
+    x[1, n // 2] = 1.0
+    x[3, :] = 0.25
+    for kwargs in ({}, {"want_amp": True}):
+        idx, freq, amp, ph, rows, _ = plan.spectrum_peaks(torch.from_numpy(x).cuda(), "rect", "one", 48000.0, **kwargs)
+        idx, amp = idx.cpu().numpy(), amp.cpu().numpy()
+        assert idx[0] == 1 and idx[1] == 1, idx
+        assert amp[0] == np.float32(2.0 / n) and amp[1] == np.float32(2.0 / n)
+        assert idx[2] == 0 and amp[2] == 0 and idx[3] == 0 and abs(amp[3] - 0.25) < 1e-6
+        if rows is not None:
+            r = rows.cpu().numpy()
+            assert np.all(r[0, 1:n // 2] == np.float32(2.0 / n)) and r[0, 0] == np.float32(1.0 / n) == r[0, n // 2]
+    # an impulse plus a small cosine at bin k: X[k] = 1 + eps N / 2 exactly representable steps -> that bin must win
+    for k in (1, 2, 255, 256, n // 4 - 1, n // 4, n // 4 + 1, n // 2 - 2, n // 2 - 1):
+        y = np.zeros((1, n))
+        y[0, 0] = 1.0
+        y[0] += (2.0 ** -6) * np.cos(2 * np.pi * k * np.arange(n) / n)
+        idx, _, amp, _, _, _ = plan.spectrum_peaks(torch.from_numpy(y.astype(np.float32)).cuda(), "rect", "one", 48000.0)
+        assert int(idx[0]) == k, (n, k, int(idx[0]))
