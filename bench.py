@@ -805,7 +805,8 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                          "kernel": kernel_label,
                          "device_copy_same_buffers_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "launch_ms_avg": launch_ms, "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
+                         "launch_ms_avg": launch_ms, "launch_ms_median": float(np.median(step_ms)) / launches_per_step,
+                         "launch_ms_min": float(np.min(step_ms)) / launches_per_step},
             "clocks": {"before": clocks_before, "under_load": clocks_load, "after": clocks_after,
                        "device_copy_under_load": copy_clocks,
                        "source": "sysfs pp_dpm_* and hwmon of /sys/class/drm/card*/device"},
