@@ -100,6 +100,8 @@ def cpu_baseline(re_rows: np.ndarray, im_rows, n: int, target_s: float = 12.0):
         "sample": f"{done} transforms of N={n} ({rows} distinct rows of the GPU batch x {reps} passes), "
                   f"{sec:.1f} s, f64 scalar C -O2, host has {os.cpu_count()} cpus",
         "transforms_per_s": done / sec,
+        # labelled extrapolation: what one pass over the GPU's batch would take at this rate, never measured
+        "extrapolated_s_per_65536_transforms": 65536 / (done / sec),
         "checksum": chk,
     }
 
@@ -848,7 +850,8 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                                                  (amp[sel].cpu().numpy().astype(np.float64),), n, "hann")
         if world == 1 and args.workload == "fft4096" and not args.no_also:
             out["also"] = {"spectrum16k": also_spectrum16k(args, dev, rank),
-                           "fft4096_f64": also_fft4096_f64(args, dev, rank, re, im)}
+                           "fft4096_f64": also_fft4096_f64(args, dev, rank, re, im),
+                           "real4096": also_real4096(args, dev, plan, re, ore, oim)}
             try:  # configs[1]: one N = 1024 frame, latency (a reported extra: never fatal to the headline)
                 lat = single_frame_latency(args, dev, iters=300, js_iters=500, js_sizes="1024")
                 out["also"]["single1024"] = {k: lat[k] for k in ("config", "unit", "dropin_spectrum_us", "dropin_forward_us",
@@ -1105,6 +1108,41 @@ def cpu_baseline_spectrum(frames: np.ndarray, n: int, window: str, target_s: flo
             "sample": f"{done} frames of N={n} ({x.shape[0]} distinct frames of the GPU stream x {reps} passes), {sec:.1f} s, "
                       f"f64 scalar C -O2: applyWindow + FFT + magnitude + one-sided scaling, plan and window reused; "
                       f"host has {os.cpu_count()} cpus"}
+
+
+def also_real4096(args, dev, plan, re, ore, oim):
+    """Radix2Fft.forward semantics on the headline's rows (real input, imaginary part taken as zero,
+    src/core/fft.ts:77-79): 4 B read + 8 B written = 12 algorithmic bytes per sample, 3 GiB per launch -- reported
+    separately, never mixed into the 16 B figure.  64 rows against the oracle."""
+    n, steps = plan.size, 10
+    batch = re.shape[0]
+    stream = torch.cuda.current_stream(dev)
+    t_ramp = time.perf_counter()
+    plan.forward(re, None, out=(ore, oim))
+    torch.cuda.synchronize(dev)
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        for _ in range(10):
+            plan.forward(re, None, out=(ore, oim))
+        torch.cuda.synchronize(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record(stream)
+    for i in range(steps):
+        plan.forward(re, None, out=(ore, oim))
+        evs[i + 1].record(stream)
+    torch.cuda.synchronize(dev)
+    ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    avg, nbytes = float(np.mean(ms)), 12 * batch * n
+    res = {"config": {"workload": f"N={n} batch={batch} Radix2Fft.forward fp32 real input", "n": n, "batch": batch},
+           "kernel": "fft_stockham_kernel<float, 12, LoadReal, StoreComplex>", "steps": steps, "ms": avg, "ms_min": float(np.min(ms)),
+           "GSample_per_s": batch * n / (avg * 1e-3) / 1e9, "algorithmic_bytes_per_launch": nbytes,
+           "GBps": nbytes / (avg * 1e-3) / 1e9, "frac": nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    if not args.no_cpu_baseline:
+        g = torch.Generator()
+        g.manual_seed(1337)
+        sel = torch.randperm(batch, generator=g)[:64].sort().values.to(dev)
+        res["parity"] = parity_vs_oracle("real", (re[sel].cpu().numpy(), None),
+                                         (ore[sel].cpu().numpy().astype(np.float64), oim[sel].cpu().numpy().astype(np.float64)), n)
+    return res
 
 
 def also_fft4096_f64(args, dev, rank: int, re32, im32):
