@@ -153,3 +153,32 @@ def test_radix_plan_layout_is_consistent():
             radices = [16] * (log2n // 4) + ([1 << (log2n % 4)] if log2n % 4 else [])
         assert int(np.prod(radices)) == n if radices else n == 1
         assert len(radices) <= 4
+
+
+def _build_c_consumer(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "abi_smoke")
+    csrc = os.path.join(ROOT, "pragma-dsp_amd", "csrc")
+    subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L" + csrc, "-lpdsp_hip", "-Wl,-rpath," + csrc, "-lm"],
+                   check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_headers_are_valid_c11_and_a_plain_c_consumer_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/pdsp_hip.h promises a C ABI: a C11 translation unit with -pedantic -Werror must compile against it (not
+    only the C++ of the library itself), link to libpdsp_hip.so and -- here, without a GPU -- get PDSP_ERR_DEVICE with a
+    message instead of a silent CPU fallback."""
+    import subprocess
+    import torch
+    for h in ("pdsp_hip.h", "pdsp_hip_dev.h"):
+        subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)], check=True, capture_output=True)
+    exe = _build_c_consumer(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_c_consumer.py runs it")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "status 10" in p.stderr and "no HIP device available" in p.stderr and "no CPU fallback" in p.stderr
