@@ -275,6 +275,12 @@ static napi_value BinFrequencies(napi_env env, napi_callback_info info) {
   if (!get_args(env, info, 4, argv) || !get_i64(env, argv[0], &size) || !get_f64(env, argv[1], &rate) ||
       !get_i64(env, argv[2], &sides) || !f64_array(env, argv[3], &out, &n))
     return NULL;
+  /* size / rate errors keep the reference's texts (the C call validates before it writes); a valid request must
+   * fit the caller's array: size/2 + 1 values one-sided, size two-sided */
+  if (size > 0 && rate > 0 && n < (size_t)(sides == PDSP_SIDES_ONE ? size / 2 + 1 : size)) {
+    napi_throw_error(env, NULL, "pdsp_napi: binFrequencies output too small");
+    return NULL;
+  }
   if (pdsp_bin_frequencies(size, rate, (int)sides, out, NULL) != PDSP_OK) return throw_pdsp(env);
   return NULL;
 }

@@ -190,3 +190,42 @@ def test_reference_suite_in_javascript_through_the_dropin(tmp_path, reallife, v0
     # 15 x 2 random cases, 1 spectrum case, 28 windows, 23 x 4 pure sines, 2 x 2 multi-tone, 1 x 2 chirp, 4 special,
     # phase: 1 + 5 x 2 + 4, scaling: 15 x 3 + 6, edge cases: 11
     assert len(res) == 30 + 1 + 28 + 92 + 4 + 2 + 4 + 15 + 51 + 11 == 238, len(res)
+
+
+@needs_node
+def test_napi_addon_argument_handling_under_address_sanitizer(tmp_path):
+    """The addon is the one piece of native code a JS caller reaches with arbitrary arguments.  An ASan + UBSan build of
+    pdsp_napi.c (CPU only: sanitizers are not available on the GPU pool) is driven with short outputs, mismatched planes,
+    bad sizes, wrong types and wrong arities: every case must end in a JS exception or a correct value, and the sanitizers
+    must stay silent.  No GPU: every compute call stops at validation or at "no HIP device"."""
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/usr/include/node/node_api.h"):
+        pytest.skip("gcc or node headers missing")
+    asan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan = subprocess.run([gcc, "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan is not installed")
+    csrc = os.path.join(ROOT, "pragma-dsp_amd", "csrc")
+    addon = str(tmp_path / "pdsp_napi.node")
+    subprocess.run([gcc, "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fPIC", "-shared", "-std=gnu11",
+                    "-Wall", "-DNODE_GYP_MODULE_NAME=pdsp_napi", "-I/usr/include/node", "-I" + os.path.join(ROOT, "include"),
+                    "-o", addon, os.path.join(csrc, "pdsp_napi.c"), "-L" + csrc, "-lpdsp_hip", "-Wl,-rpath," + csrc],
+                   check=True, capture_output=True, text=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               LD_PRELOAD=asan + (":" + ubsan if os.path.exists(ubsan) else ""))
+    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "asan_cases.js"), addon], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]
+    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    log = {name: (kind, val) for name, kind, val in json.loads(p.stdout.strip().splitlines()[-1])}
+    assert log["windowMake"][0] == "ok" and abs(float(log["windowMake"][1]) - 0.0008984113451827869) < 1e-15
+    assert log["nextPow2"] == ("ok", "1,1,8,2048,4294967296")
+    assert log["binFrequencies"] == ("ok", "0,6000,12000,18000,24000") and log["fftShift"] == ("ok", "2,3,4,0,1")
+    assert log["planCreate 12"] == ("throws", "FFT size must be power of two, got 12")
+    assert log["windowMake size 0"] == ("throws", "Window size must be positive, got 0")
+    assert log["applyWindow length mismatch"] == ("throws", "Window length must match input length.")
+    for name in ("windowMake short out", "binFrequencies short out", "fftShift short out", "magnitude short out",
+                 "phase mismatched planes", "spectrum short out", "spectrumBatch short out", "transform wrong types",
+                 "wrong argument count", "planCreate 0", "planCreate -8", "windowMake bad type", "binFrequencies rate 0",
+                 "spectrum bad size"):
+        assert log[name][0] == "throws", (name, log[name])
