@@ -34,7 +34,7 @@ Other workloads (parity-checked elsewhere; here for DESIGN.md's numbers):
                            streamed in chunks of --chunk frames
   --workload real4096      Radix2Fft.forward semantics (real in, 12 B/sample)
   --workload fft4096_f64   configs[2]'s shape in f64 (32 B/sample)
-  --workload fft16k / spectrum256 / peaks16k / single1024 (configs[1], latency) / stream (PCIe-inclusive)
+  --workload fft16k / spectrum256 / peaks16k / single1024 (configs[1], latency) / stream, hostbatch (PCIe-inclusive)
 """
 from __future__ import annotations
 
@@ -293,6 +293,67 @@ def stream_throughput(args, dev) -> int:
     return 0
 
 
+def host_batch_throughput(args, dev) -> int:
+    """The batched host boundary itself (what the JS drop-in's spectrumBatch() binds): f64 frames in host memory ->
+    pdsp_spectrum_batch_host_f64 -> f64 amplitude / phase rows + SpectrumPeak records in host memory, 2^26 samples per
+    call.  Large calls are cut into chunks on several workers inside the library (staging, both PCIe directions and
+    the kernels overlap); PDSP_HOST_THREADS=1 is the one-shot sequence of rounds 1-3, timed beside it.  PCIe- and
+    host-bound: DESIGN.md's PCIe-inclusive note, never `value` of the headline metric.  16 rows per case against
+    the oracle's spectrum()."""
+    import ctypes as C
+    import oracle
+    import pragma_dsp_amd as pd
+    from pragma_dsp_amd._capi import Peak, check, dptr
+    lib = pd.lib
+    rows = []
+    env0 = os.environ.get("PDSP_HOST_THREADS")
+    for n in (1024, 4096, 16384):
+        batch = (1 << 26) // n
+        rng = np.random.default_rng(n)
+        x = rng.standard_normal((batch, n)) + np.sin(2 * np.pi * 37 * np.arange(n) / n)
+        bins = n // 2 + 1
+        freq, amp, ph = np.empty(bins), np.empty((batch, bins)), np.empty((batch, bins))
+        peaks = (Peak * batch)()
+        pick = np.linspace(0, batch - 1, 16).astype(int)
+        want = [oracle.spectrum(x[r], sample_rate=48000.0, fft_size=n, window="hann") for r in pick]
+        for bits in (64, 32):
+            prev = lib.pdsp_set_host_precision(bits)
+            try:
+                for threads in (None, "1"):
+                    if threads is None:
+                        os.environ.pop("PDSP_HOST_THREADS", None) if env0 is None else os.environ.__setitem__("PDSP_HOST_THREADS", env0)
+                    else:
+                        os.environ["PDSP_HOST_THREADS"] = threads
+                    best = None
+                    for _ in range(4):
+                        t0 = time.perf_counter()
+                        check(lib.pdsp_spectrum_batch_host_f64(dptr(x), batch, n, 48000.0, n, 1, 0, dptr(freq), dptr(amp),
+                                                               dptr(ph), peaks, None))
+                        sec = time.perf_counter() - t0
+                        best = sec if best is None else min(best, sec)
+                    err = max(float(np.abs(amp[r] - w["amplitude"]).max() / w["amplitude"].max()) for r, w in zip(pick, want))
+                    peaks_ok = all(peaks[int(r)].index == w["peak"]["index"] for r, w in zip(pick, want))
+                    rows.append({"n": n, "batch": batch, "precision": bits,
+                                 "mode": "chunked on the library's workers" if threads is None else "one-shot sequence (PDSP_HOST_THREADS=1)",
+                                 "ms": best * 1e3, "GSample_per_s": batch * n / best / 1e9,
+                                 "host_GBps_in_plus_out": (x.nbytes + amp.nbytes + ph.nbytes) / best / 1e9,
+                                 "max_rel_err_16_rows": err, "tolerance": 1e-12 if bits == 64 else 1e-5,
+                                 "ok": bool(err <= (1e-12 if bits == 64 else 1e-5) and peaks_ok)})
+            finally:
+                lib.pdsp_set_host_precision(prev)
+                if env0 is None:
+                    os.environ.pop("PDSP_HOST_THREADS", None)
+                else:
+                    os.environ["PDSP_HOST_THREADS"] = env0
+    print(json.dumps({"metric": "pdsp_spectrum_batch_host_f64 host-to-host throughput (PCIe-inclusive)", "unit": "GSample/s",
+                      "higher_is_better": True, "value": max(r["GSample_per_s"] for r in rows), "n_gpus": 1, "steps": 4,
+                      "warmup": 0, "dtype": "f64/f32", "data": "synthetic",
+                      "config": {"workload": "spectrumBatch: 2^26 samples of host f64 frames per call, hann, one-sided, "
+                                             "amplitude + phase + peak records back in host f64"},
+                      "host_cpus": os.cpu_count(), "rows": rows}), flush=True)
+    return 0 if all(r["ok"] for r in rows) else 4
+
+
 def parity_vs_oracle(kind: str, inputs, outputs, n: int, window: str | None = None, tol: float = 1e-5):
     """Outside the timed region: rows of the very buffers the timed steps wrote, checked against the
     CPU oracle (the checker, never the thing measured).  Stated fp32 tolerance of the path:
@@ -476,7 +537,7 @@ def parse_args(argv):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft4096_f64", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024", "stream"])
+    ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft4096_f64", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024", "stream", "hostbatch"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None, help="spectrum256 only: another frame size (development sweeps)")
     ap.add_argument("--chunk", type=int, default=16384, help="frames per launch for spectrum16k")
@@ -611,6 +672,8 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
         return 0
     if args.workload == "stream":
         return stream_throughput(args, dev)
+    if args.workload == "hostbatch":
+        return host_batch_throughput(args, dev)
 
     if args.workload in ("spectrum16k", "peaks16k"):
         n, per_gpu = 16384, args.batch or (1 << 20)

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pdsp_hip.h"
@@ -225,6 +226,8 @@ struct pdsp_plan {
   size_t h_bytes = 0;
   void *d_stage = nullptr;
   size_t d_bytes = 0;
+  // batched host calls large enough to be cut into chunks (run_chunked): one stream per staging slot
+  std::vector<hipStream_t> slot_streams;
 };
 
 template <typename T> Tables<T> &tables(pdsp_plan *p);
@@ -1571,11 +1574,160 @@ int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long 
   return PDSP_OK;
 }
 
+// ---- chunked host calls -------------------------------------------------------------------------------------
+// A batched host-f64 call moves every sample through the CPU twice (the caller's f64 rows <-> pinned staging), over
+// PCIe twice, and through a kernel that needs a few percent of that time.  As ONE stage -> copy -> launch -> copy ->
+// unstage sequence each step waits for the one before it and one core does all the staging: ~0.4 GSample/s at
+// N = 4096 whatever the card does.  Calls above kChunkedMinBytes of staging are cut into chunks of ~kChunkInBytes of
+// input rows instead; K workers (the calling thread and K - 1 helpers that live for the call) each own one staging
+// slot and one stream and draw chunks from a shared counter: fill the slot, H2D, the same kernels the one-shot path
+// launches, D2H, wait for the stream, unstage (+ findPeak).  Inside a worker the steps stay in order; across workers
+// staging, both PCIe directions and the kernels overlap.  Row b of the result is the one-shot result of row b bit
+// for bit (the kernels work row by row and the variant does not depend on the row count).
+// PDSP_HOST_THREADS sets K (1 = the one-shot sequence; default: half the cores this process may run on, 2 ... 6).
+constexpr size_t kChunkInBytes = (size_t)2 << 20;
+constexpr size_t kChunkedMinBytes = (size_t)8 << 20;
+
+// multipass: the size runs on the multi-pass paths, whose scratch planes come from the engine's stream-ordered pool --
+// planes freed on one stream are not reusable on another before a synchronisation, so many streams grow the pool
+// through the driver instead of overlapping (f64 N = 16384 rows: 20 ms on 2 workers, 49-57 ms on 4-8): two workers.
+int host_workers(bool multipass = false) {
+  long v = 0;
+  if (const char *e = getenv("PDSP_HOST_THREADS")) v = atol(e);
+  if (v <= 0) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    v = hc ? (long)(hc / 2) : 2;
+    if (v < 2) v = 2;
+    if (v > 6) v = 6;
+  }
+  if (multipass && v > 2) v = 2;
+  return (int)(v > 16 ? 16 : v);
+}
+
+inline bool host_ranges_overlap(const void *a, size_t a_bytes, const void *b, size_t b_bytes) {
+  const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+  return a && b && a_bytes && b_bytes && a0 < b0 + b_bytes && b0 < a0 + a_bytes;
+}
+
+struct ChunkJob {
+  long long first = 0, count = 0;  // rows [first, first + count) of the call
+  int slot = 0;                    // staging slot of the worker that runs it
+  hipStream_t stream = nullptr;
+};
+
+// body(job) -> pdsp status, error text in the running thread's g_err.  Caller holds plan->mu and has staged
+// `workers` slots (ensure_stage).  The first failure stops the hand-out of chunks and is what the call returns.
+template <class Body>
+int run_chunked(pdsp_plan *plan, long long rows, long long rows_per_chunk, int workers, Body body) {
+  const long long nchunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  if (workers > nchunks) workers = (int)nchunks;
+  while ((long long)plan->slot_streams.size() < workers) {
+    hipStream_t st = nullptr;
+    PDSP_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    plan->slot_streams.push_back(st);
+  }
+  std::atomic<long long> next{0};
+  std::atomic<int> status{PDSP_OK};
+  std::mutex err_mu;
+  std::string err_text;
+  auto report = [&](int rc) {
+    std::lock_guard<std::mutex> lk(err_mu);
+    if (status.load() == PDSP_OK) {
+      err_text = g_err;
+      status.store(rc);
+    }
+  };
+  auto worker = [&](int w) {
+    const hipStream_t st = plan->slot_streams[(size_t)w];
+    const hipError_t e = hipSetDevice(plan->device);  // helpers start on device 0
+    if (e != hipSuccess) {
+      report(fail(PDSP_ERR_DEVICE, "HIP error %d (%s) at hipSetDevice", (int)e, hipGetErrorString(e)));
+      return;
+    }
+    while (status.load() == PDSP_OK) {
+      const long long c = next.fetch_add(1);
+      if (c >= nchunks) break;
+      ChunkJob job;
+      job.first = c * rows_per_chunk;
+      job.count = rows - job.first < rows_per_chunk ? rows - job.first : rows_per_chunk;
+      job.slot = w;
+      job.stream = st;
+      if (const int rc = body(job)) {
+        report(rc);
+        break;
+      }
+    }
+    (void)hipStreamSynchronize(st);  // nothing of this call stays in flight on the slot, on any exit
+  };
+  std::vector<std::thread> helpers;
+  helpers.reserve((size_t)workers);
+  for (int w = 1; w < workers; ++w) {
+    try {
+      helpers.emplace_back(worker, w);
+    } catch (...) {
+      break;  // no more threads to be had: the workers that did start share the chunks
+    }
+  }
+  worker(0);
+  for (std::thread &t : helpers) t.join();
+  if (status.load() != PDSP_OK) {
+    g_err = err_text;
+    return status.load();
+  }
+  return PDSP_OK;
+}
+
+template <typename T>
+inline void rows_to_stage(T *dst, const double *src, size_t count) {
+  if constexpr (sizeof(T) == sizeof(double)) std::memcpy(dst, src, count * sizeof(double));
+  else
+    for (size_t i = 0; i < count; ++i) dst[i] = (T)src[i];
+}
+template <typename T>
+inline void stage_to_rows(double *dst, const T *src, size_t count) {
+  if constexpr (sizeof(T) == sizeof(double)) std::memcpy(dst, src, count * sizeof(double));
+  else
+    for (size_t i = 0; i < count; ++i) dst[i] = (double)src[i];
+}
+
 // Radix2Fft.transform for `batch` host rows in precision T (f64 at the boundary either way).
 template <typename T>
 int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const double *im_in, double *re_out,
                    double *im_out, int inverse) {
   const size_t cnt = (size_t)batch * (size_t)plan->n;
+  {
+    // many rows: chunks on several workers (run_chunked); planes that overlap each other in host memory keep the
+    // one-shot sequence, which has read every input before it writes any output
+    const size_t row_bytes = (size_t)plan->n * sizeof(T), in_bytes = cnt * sizeof(double);
+    const long long per_chunk = (long long)(kChunkInBytes / ((im_in ? 2 : 1) * row_bytes));
+    const int workers = host_workers(tables<T>(plan).log2n1 > 0);
+    const bool overlap = host_ranges_overlap(re_in, in_bytes, re_out, in_bytes) ||
+                         host_ranges_overlap(re_in, in_bytes, im_out, in_bytes) ||
+                         host_ranges_overlap(im_in, in_bytes, re_out, in_bytes) ||
+                         host_ranges_overlap(im_in, in_bytes, im_out, in_bytes);
+    if (workers >= 2 && per_chunk >= 1 && batch >= 2 * per_chunk && 4 * cnt * sizeof(T) >= kChunkedMinBytes && !overlap) {
+      const size_t slot = 4 * (size_t)per_chunk * (size_t)plan->n;  // elements: re | im | out re | out im
+      const int k = (long long)workers < (batch + per_chunk - 1) / per_chunk ? workers : (int)((batch + per_chunk - 1) / per_chunk);
+      if (int rc = ensure_stage(plan, (size_t)k * slot * sizeof(T))) return rc;
+      const size_t n = (size_t)plan->n;
+      return run_chunked(plan, batch, per_chunk, k, [&](const ChunkJob &job) -> int {
+        const size_t c = (size_t)job.count * n, off = (size_t)job.first * n;
+        T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
+        rows_to_stage<T>(h, re_in + off, c);
+        if (im_in) rows_to_stage<T>(h + c, im_in + off, c);
+        PDSP_HIP_TRY(hipMemcpyAsync(d, h, (im_in ? 2 : 1) * c * sizeof(T), hipMemcpyHostToDevice, job.stream));
+        int rc;
+        if (inverse) rc = run_complex<T>(plan, job.count, d + c, d, d + 3 * c, d + 2 * c, T(1) / (T)plan->n, job.stream);
+        else rc = run_complex<T>(plan, job.count, d, im_in ? d + c : nullptr, d + 2 * c, d + 3 * c, T(1), job.stream);
+        if (rc) return rc;
+        PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * c, d + 2 * c, 2 * c * sizeof(T), hipMemcpyDeviceToHost, job.stream));
+        PDSP_HIP_TRY(hipStreamSynchronize(job.stream));
+        stage_to_rows<T>(re_out + off, h + 2 * c, c);
+        stage_to_rows<T>(im_out + off, h + 3 * c, c);
+        return PDSP_OK;
+      });
+    }
+  }
   if (int rc = ensure_stage(plan, 4 * cnt * sizeof(T))) return rc;
   T *h_re = (T *)plan->h_stage, *h_im = h_re + cnt, *h_ore = h_im + cnt, *h_oim = h_ore + cnt;
   T *d_re = (T *)plan->d_stage, *d_im = d_re + cnt, *d_ore = d_im + cnt, *d_oim = d_ore + cnt;
@@ -1655,12 +1807,68 @@ int polar_host_t(const double *re, const double *im, long long n_, double *out, 
 // `batch` frames of spectrum() (each `len` samples, contiguous) in precision T; plan->mu held by the
 // caller.  One frame (the drop-in spectrum()) and many (spectrumBatch) run the same kernel variant per
 // row, so row b of a batch equals the one-frame call on frame b bit for bit.
+// findPeak on the host over the f64 amplitudes of rows [first, first + count): exact strict-'>' and first-wins
+// behaviour (spectrum.ts:74-105), peak.frequency from the call's one frequency axis.
+inline void host_peaks(const double *freq, const double *amp_out, const double *phase_out, long long bins,
+                       long long first, long long count, pdsp_peak *peak_out) {
+  for (long long b = first; b < first + count; ++b) {
+    const double *a = amp_out + (size_t)b * (size_t)bins, *p = phase_out + (size_t)b * (size_t)bins;
+    const long long pk = pdsp_find_peak_f64(a, bins);
+    peak_out[b].index = (int32_t)pk;
+    peak_out[b].frequency = freq[pk];
+    peak_out[b].amplitude = a[pk];
+    peak_out[b].phase = p[pk];
+  }
+}
+
 template <typename T>
 int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int window, int sides, double *amp_out,
-                    double *phase_out, long long batch = 1) {
+                    double *phase_out, long long batch, const double *freq, pdsp_peak *peak_out) {
   const long long n = plan->n;
   const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
   const long long used = len < n ? len : n;
+  {
+    // many frames: chunks on several workers (run_chunked)
+    const size_t frame_bytes = (size_t)n * sizeof(T);
+    const long long per_chunk = (long long)(kChunkInBytes / frame_bytes);
+    const int workers = host_workers(tables<T>(plan).log2n1 > 0 && !tables<T>(plan).tw_half);  // packed-real frames: one pass
+    const size_t in_b = (size_t)batch * (size_t)(len > 0 ? len : 1) * sizeof(double), out_b = (size_t)batch * (size_t)bins * sizeof(double);
+    const bool overlap = host_ranges_overlap(samples, in_b, amp_out, out_b) || host_ranges_overlap(samples, in_b, phase_out, out_b);
+    if (workers >= 2 && per_chunk >= 1 && batch >= 2 * per_chunk && len > 0 &&
+        (size_t)batch * (size_t)(n + 2 * bins) * sizeof(T) >= kChunkedMinBytes && !overlap) {
+      const T *d_window = nullptr;
+      if (n != 1 && window != PDSP_WIN_RECT) {
+        if (int rc = plan_window<T>(plan, window, &d_window)) return rc;  // built once, before the workers read it
+      }
+      // slot (elements): [per_chunk frames of n][per_chunk rows of amp][per_chunk rows of phase], 16-byte aligned parts
+      const size_t amp_off = ((size_t)per_chunk * (size_t)n + 3) & ~(size_t)3;
+      const size_t ph_off = (amp_off + (size_t)per_chunk * (size_t)bins + 3) & ~(size_t)3;
+      const size_t slot = (ph_off + (size_t)per_chunk * (size_t)bins + 3) & ~(size_t)3;
+      const long long nchunks = (batch + per_chunk - 1) / per_chunk;
+      const int k = (long long)workers < nchunks ? workers : (int)nchunks;
+      if (int rc = ensure_stage(plan, (size_t)k * slot * sizeof(T))) return rc;
+      return run_chunked(plan, batch, per_chunk, k, [&](const ChunkJob &job) -> int {
+        T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
+        for (long long b = 0; b < job.count; ++b) {
+          T *dst = h + (size_t)b * (size_t)n;
+          rows_to_stage<T>(dst, samples + (size_t)(job.first + b) * (size_t)len, (size_t)used);
+          if (used < n) std::memset(dst + used, 0, (size_t)(n - used) * sizeof(T));
+        }
+        const size_t rows = (size_t)job.count * (size_t)bins;
+        PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)job.count * frame_bytes, hipMemcpyHostToDevice, job.stream));
+        if (int rc = spectrum_impl<T>(plan, job.count, d, n, n, d_window, sides, d + amp_off, d + ph_off, nullptr, nullptr,
+                                      1.0, job.stream))
+          return rc;
+        PDSP_HIP_TRY(hipMemcpyAsync(h + amp_off, d + amp_off, rows * sizeof(T), hipMemcpyDeviceToHost, job.stream));
+        PDSP_HIP_TRY(hipMemcpyAsync(h + ph_off, d + ph_off, rows * sizeof(T), hipMemcpyDeviceToHost, job.stream));
+        PDSP_HIP_TRY(hipStreamSynchronize(job.stream));
+        stage_to_rows<T>(amp_out + (size_t)job.first * (size_t)bins, h + amp_off, rows);
+        stage_to_rows<T>(phase_out + (size_t)job.first * (size_t)bins, h + ph_off, rows);
+        if (peak_out) host_peaks(freq, amp_out, phase_out, bins, job.first, job.count, peak_out);
+        return PDSP_OK;
+      });
+    }
+  }
   // staging: [batch frames of n][batch rows of amp][batch rows of phase]; rows start 16-byte aligned
   const size_t rows = (size_t)batch * (size_t)bins, frames_sz = (size_t)batch * (size_t)n;
   const size_t amp_off = (frames_sz + 3) & ~(size_t)3, ph_off = (amp_off + rows + 3) & ~(size_t)3;
@@ -1687,6 +1895,7 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int w
   PDSP_HIP_TRY(hipStreamSynchronize(s));
   for (size_t i = 0; i < rows; ++i) amp_out[i] = (double)h[amp_off + i];
   for (size_t i = 0; i < rows; ++i) phase_out[i] = (double)h[ph_off + i];
+  if (peak_out) host_peaks(freq, amp_out, phase_out, bins, 0, batch, peak_out);
   return PDSP_OK;
 }
 
@@ -1900,6 +2109,10 @@ int pdsp_plan_destroy(pdsp_plan *plan) {
       (void)hipStreamSynchronize(plan->stream);
       (void)hipStreamDestroy(plan->stream);
     }
+    for (hipStream_t st : plan->slot_streams) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
     // a plan of a multi-pass size that drew scratch planes: the freed planes go back to the device with it
     const bool multipass = plan->t32.log2n1 > 0 || plan->t64.log2n1 > 0;
     plan->t32.release();
@@ -2085,22 +2298,11 @@ int pdsp_spectrum_batch_host_f64(const double *samples, long long batch, long lo
   const bool f64 = host_precision() == 64 && (plan->t64.tw_half || plan->t64.tw);
   static const double kNoSample = 0.0;  // len == 0: every frame is all zero padding
   const double *src = len > 0 ? samples : &kNoSample;
-  const int rc_run = f64 ? spectrum_host_t<double>(plan, src, len, window, sides, amp_out, phase_out, batch)
-                         : spectrum_host_t<float>(plan, src, len, window, sides, amp_out, phase_out, batch);
+  // findPeak runs on the host over the f64 amplitudes (host_peaks), inside the call's staging loop
+  const int rc_run = f64 ? spectrum_host_t<double>(plan, src, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out)
+                         : spectrum_host_t<float>(plan, src, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out);
   trim_stage(plan);
-  if (rc_run) return rc_run;
-  if (peak_out) {
-    // findPeak on the host over the f64 amplitudes: exact strict-'>' and first-wins behaviour
-    for (long long b = 0; b < batch; ++b) {
-      const double *a = amp_out + (size_t)b * (size_t)bins, *p = phase_out + (size_t)b * (size_t)bins;
-      const long long pk = pdsp_find_peak_f64(a, bins);
-      peak_out[b].index = (int32_t)pk;
-      peak_out[b].frequency = freq_out[pk];
-      peak_out[b].amplitude = a[pk];
-      peak_out[b].phase = p[pk];
-    }
-  }
-  return PDSP_OK;
+  return rc_run;
 }
 
 }  // extern "C"

@@ -1,0 +1,146 @@
+"""Batched host-f64 calls large enough to be cut into chunks on several workers (pdsp_capi.hip, run_chunked):
+pdsp_spectrum_batch_host_f64 -- what the JS drop-in's spectrumBatch() binds, the map of the reference's
+spectrumStream (src/effect/index.ts:190-194) -- and pdsp_fft_transform_host_f64 on many rows
+(Radix2Fft.transform, src/core/fft.ts:89-151).  The chunked result must equal the one-shot sequence
+(PDSP_HOST_THREADS=1) bit for bit, and both must meet the oracle at the precision's tolerance."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def capi():
+    import pragma_dsp_amd  # noqa: F401
+    from pragma_dsp_amd import _capi
+    prev = _capi.lib.pdsp_set_host_precision(0)
+    env = os.environ.get("PDSP_HOST_THREADS")
+    yield _capi
+    _capi.lib.pdsp_set_host_precision(prev)
+    if env is None:
+        os.environ.pop("PDSP_HOST_THREADS", None)
+    else:
+        os.environ["PDSP_HOST_THREADS"] = env
+
+
+def _spectrum_batch(capi, x, n, window, sides, threads=None):
+    if threads is not None:  # (never from concurrent threads: setenv beside another thread's getenv is a race)
+        os.environ["PDSP_HOST_THREADS"] = str(threads)
+    lib = capi.lib
+    batch, length = x.shape
+    bins = n // 2 + 1 if sides == 0 else n
+    freq = np.full(bins, np.nan)
+    amp = np.full((batch, bins), np.nan)
+    ph = np.full((batch, bins), np.nan)
+    peaks = (capi.Peak * batch)()
+    nb = C.c_longlong(0)
+    capi.check(lib.pdsp_spectrum_batch_host_f64(capi.dptr(x), batch, length, 48000.0, n, window, sides, capi.dptr(freq),
+                                                capi.dptr(amp), capi.dptr(ph), peaks, C.byref(nb)))
+    assert nb.value == bins
+    pk = np.array([(p.index, p.frequency, p.amplitude, p.phase) for p in peaks])
+    return freq, amp, ph, pk
+
+
+@pytest.mark.parametrize("precision,tol", [(64, 1e-12), (32, 1e-5)])
+@pytest.mark.parametrize("n,length,batch,window,sides", [
+    (1024, 1024, 1501, 1, 0),    # hann, one-sided; the last chunk is partial
+    (4096, 3000, 700, 3, 0),     # blackman over zero-padded frames (buildFrame, spectrum.ts:36-43)
+    (2048, 2500, 1100, 0, 1),    # rect, two-sided, frames longer than N are truncated
+    (16384, 16384, 90, 2, 0),    # hamming at configs[3]'s frame size
+])
+def test_chunked_spectrum_batch_equals_one_shot_and_oracle(capi, oracle_mod, precision, tol, n, length, batch, window, sides):
+    capi.lib.pdsp_set_host_precision(precision)
+    rng = np.random.default_rng(1337 + n)
+    t = np.arange(length)
+    x = rng.standard_normal((batch, length)) + 2.0 * np.sin(2 * np.pi * rng.integers(3, n // 4, (batch, 1)) * t / n)
+    one = _spectrum_batch(capi, x, n, window, sides, 1)
+    for threads in (2, 5):
+        got = _spectrum_batch(capi, x, n, window, sides, threads)
+        for a, b, what in zip(one, got, ("frequencies", "amplitude", "phase", "peaks")):
+            assert np.array_equal(a, b), f"{what}: chunked on {threads} workers differs from the one-shot sequence"
+    # the oracle's spectrum() on rows drawn over the whole batch (first, last, chunk boundaries)
+    kinds = ["rect", "hann", "hamming", "blackman"]
+    rows = sorted({0, 1, batch // 2, batch - 2, batch - 1} | set(int(r) for r in rng.integers(0, batch, 6)))
+    for r in rows:
+        want = oracle_mod.spectrum(x[r], sample_rate=48000.0, fft_size=n, window=kinds[window],
+                                   sides="one" if sides == 0 else "two")
+        scale = np.abs(want["amplitude"]).max()
+        assert np.abs(one[1][r] - want["amplitude"]).max() <= tol * scale
+        assert np.array_equal(one[0], want["frequencies"])
+        if sides == 0:  # the two-sided peak may be the oracle's mirror bin
+            assert int(one[3][r][0]) == want["peak"]["index"]
+            assert abs(one[3][r][2] - want["peak"]["amplitude"]) <= tol * scale
+
+
+def _transform(capi, plan, re, im, inverse, threads, out=None):
+    os.environ["PDSP_HOST_THREADS"] = str(threads)
+    batch, n = re.shape
+    ore, oim = out if out is not None else (np.full_like(re, np.nan), np.full_like(re, np.nan))
+    capi.check(capi.lib.pdsp_fft_transform_host_f64(plan, batch, n, capi.dptr(re), capi.dptr(im) if im is not None else None,
+                                                    capi.dptr(ore), capi.dptr(oim), inverse))
+    return ore, oim
+
+
+@pytest.mark.parametrize("precision,tol", [(64, 1e-12), (32, 1e-5)])
+@pytest.mark.parametrize("n,batch", [(1024, 2100), (4096, 530), (8192, 300)])
+def test_chunked_transform_equals_one_shot_and_oracle(capi, oracle_mod, precision, tol, n, batch):
+    capi.lib.pdsp_set_host_precision(precision)
+    rng = np.random.default_rng(7 + n)
+    re = rng.standard_normal((batch, n))
+    im = rng.standard_normal((batch, n))
+    plan = C.c_void_p()
+    capi.check(capi.lib.pdsp_plan_create(n, -1, C.byref(plan)))
+    try:
+        oplan = oracle_mod.Plan(n)
+        rows = [0, 1, batch // 3, batch - 1]
+        for imag, inverse in ((im, 0), (None, 0), (im, 1)):
+            one = _transform(capi, plan, re, imag, inverse, 1)
+            many = _transform(capi, plan, re, imag, inverse, 4)
+            assert np.array_equal(one[0], many[0]) and np.array_equal(one[1], many[1])
+            if inverse:
+                wre, wim = oplan.inverse(re[rows], im[rows])
+            elif imag is None:
+                wre, wim = oplan.forward(re[rows])
+            else:
+                wre, wim = oplan.forward_complex(re[rows], im[rows])
+            want = wre + 1j * wim
+            got = many[0][rows] + 1j * many[1][rows]
+            assert (np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)).max() <= tol
+        # output planes that ARE the input planes: the call keeps the one-shot sequence (every input is read
+        # before any output is written) and still returns the transform
+        want = _transform(capi, plan, re, im, 0, 1)
+        re2, im2 = re.copy(), im.copy()
+        _transform(capi, plan, re2, im2, 0, 4, out=(re2, im2))
+        assert np.array_equal(re2, want[0]) and np.array_equal(im2, want[1])
+    finally:
+        capi.lib.pdsp_plan_destroy(plan)
+
+
+def test_chunked_calls_from_two_threads(capi, oracle_mod):
+    """Two host threads, each in a chunked spectrumBatch of its own size (own cached plans), at the same time."""
+    capi.lib.pdsp_set_host_precision(64)
+    rng = np.random.default_rng(99)
+    cases = [(1024, rng.standard_normal((1300, 1024))), (2048, rng.standard_normal((700, 2048)))]
+    want = [_spectrum_batch(capi, x, n, 1, 0, 1) for n, x in cases]
+    os.environ["PDSP_HOST_THREADS"] = "3"
+    got = [None, None]
+    errs = []
+
+    def run(i):
+        try:
+            for _ in range(3):
+                got[i] = _spectrum_batch(capi, cases[i][1], cases[i][0], 1, 0)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for w, g in zip(want, got):
+        for a, b in zip(w, g):
+            assert np.array_equal(a, b)
