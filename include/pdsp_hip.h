@@ -298,11 +298,22 @@ PDSP_API int pdsp_spectrum_host_f64(const double *samples, long long len, double
 /* The same on `batch` frames of `len` samples each (contiguous) in ONE call -- the map of the
  * reference's spectrumStream (src/effect/index.ts:190-194) batched onto the device.  freq_out holds
  * the one frequency axis (bins values); amp_out / phase_out batch*bins; peak_out batch records.
- * Row b equals pdsp_spectrum_host_f64 on frame b bit for bit. */
+ * Row b equals pdsp_spectrum_host_f64 on frame b bit for bit.  Calls with 8 MiB or more of staging are cut into
+ * chunks that several host threads (PDSP_HOST_THREADS; default half the cores, 2 ... 6; 1 = none) stage, copy and
+ * launch concurrently on streams of their own -- the results do not depend on it. */
 PDSP_API int pdsp_spectrum_batch_host_f64(const double *frames, long long batch, long long len,
                                           double sample_rate, long long fft_size, int window, int sides,
                                           double *freq_out, double *amp_out, double *phase_out,
                                           pdsp_peak *peak_out, long long *bins_out);
+
+/* The same with ONE POINTER PER FRAME: rows[b] points at the `len` samples of frame b, anywhere in host memory --
+ * the Iterable<ArrayLike<number>> of spectrumStream (src/effect/index.ts:190-194) as a JS caller holds it, an array
+ * of Float64Arrays, taken as it stands instead of being flattened into one buffer first (a copy of 8 bytes per
+ * sample on the caller's one thread).  Same outputs, same bit-for-bit rule. */
+PDSP_API int pdsp_spectrum_rows_host_f64(const double *const *rows, long long batch, long long len,
+                                         double sample_rate, long long fft_size, int window, int sides,
+                                         double *freq_out, double *amp_out, double *phase_out,
+                                         pdsp_peak *peak_out, long long *bins_out);
 
 #ifdef __cplusplus
 }

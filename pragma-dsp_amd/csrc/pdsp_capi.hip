@@ -1821,9 +1821,12 @@ inline void host_peaks(const double *freq, const double *amp_out, const double *
   }
 }
 
+// Frame b starts at row_ptrs[b] when row_ptrs is given (pdsp_spectrum_rows_host_f64), else at samples + b * len.
 template <typename T>
-int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int window, int sides, double *amp_out,
-                    double *phase_out, long long batch, const double *freq, pdsp_peak *peak_out) {
+int spectrum_host_t(pdsp_plan *plan, const double *samples, const double *const *row_ptrs, long long len, int window,
+                    int sides, double *amp_out, double *phase_out, long long batch, const double *freq,
+                    pdsp_peak *peak_out) {
+  auto frame = [&](long long b) { return row_ptrs ? row_ptrs[b] : samples + (size_t)b * (size_t)len; };
   const long long n = plan->n;
   const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
   const long long used = len < n ? len : n;
@@ -1833,7 +1836,14 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int w
     const long long per_chunk = (long long)(kChunkInBytes / frame_bytes);
     const int workers = host_workers(tables<T>(plan).log2n1 > 0 && !tables<T>(plan).tw_half);  // packed-real frames: one pass
     const size_t in_b = (size_t)batch * (size_t)(len > 0 ? len : 1) * sizeof(double), out_b = (size_t)batch * (size_t)bins * sizeof(double);
-    const bool overlap = host_ranges_overlap(samples, in_b, amp_out, out_b) || host_ranges_overlap(samples, in_b, phase_out, out_b);
+    bool overlap = false;
+    if (row_ptrs) {
+      for (long long b = 0; b < batch && !overlap; ++b)
+        overlap = host_ranges_overlap(row_ptrs[b], (size_t)len * sizeof(double), amp_out, out_b) ||
+                  host_ranges_overlap(row_ptrs[b], (size_t)len * sizeof(double), phase_out, out_b);
+    } else {
+      overlap = host_ranges_overlap(samples, in_b, amp_out, out_b) || host_ranges_overlap(samples, in_b, phase_out, out_b);
+    }
     if (workers >= 2 && per_chunk >= 1 && batch >= 2 * per_chunk && len > 0 &&
         (size_t)batch * (size_t)(n + 2 * bins) * sizeof(T) >= kChunkedMinBytes && !overlap) {
       const T *d_window = nullptr;
@@ -1851,7 +1861,7 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int w
         T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
         for (long long b = 0; b < job.count; ++b) {
           T *dst = h + (size_t)b * (size_t)n;
-          rows_to_stage<T>(dst, samples + (size_t)(job.first + b) * (size_t)len, (size_t)used);
+          rows_to_stage<T>(dst, frame(job.first + b), (size_t)used);
           if (used < n) std::memset(dst + used, 0, (size_t)(n - used) * sizeof(T));
         }
         const size_t rows = (size_t)job.count * (size_t)bins;
@@ -1876,7 +1886,7 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int w
   if (int rc = ensure_stage(plan, total * sizeof(T))) return rc;
   T *h = (T *)plan->h_stage, *d = (T *)plan->d_stage;
   for (long long b = 0; b < batch; ++b) {
-    const double *src = samples + (size_t)b * (size_t)len;
+    const double *src = frame(b);
     T *dst = h + (size_t)b * (size_t)n;
     for (long long i = 0; i < used; ++i) dst[i] = (T)src[i];
     for (long long i = used; i < n; ++i) dst[i] = T(0);
@@ -1898,6 +1908,10 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, long long len, int w
   if (peak_out) host_peaks(freq, amp_out, phase_out, bins, 0, batch, peak_out);
   return PDSP_OK;
 }
+
+int spectrum_frames_host(const double *samples, const double *const *rows, long long batch, long long len,
+                         double sample_rate, long long fft_size, int window, int sides, double *freq_out,
+                         double *amp_out, double *phase_out, pdsp_peak *peak_out, long long *bins_out);
 
 }  // namespace
 
@@ -2273,8 +2287,31 @@ int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_r
 int pdsp_spectrum_batch_host_f64(const double *samples, long long batch, long long len, double sample_rate,
                                  long long fft_size, int window, int sides, double *freq_out, double *amp_out,
                                  double *phase_out, pdsp_peak *peak_out, long long *bins_out) {
+  return spectrum_frames_host(samples, nullptr, batch, len, sample_rate, fft_size, window, sides, freq_out, amp_out,
+                              phase_out, peak_out, bins_out);
+}
+
+int pdsp_spectrum_rows_host_f64(const double *const *rows, long long batch, long long len, double sample_rate,
+                                long long fft_size, int window, int sides, double *freq_out, double *amp_out,
+                                double *phase_out, pdsp_peak *peak_out, long long *bins_out) {
+  if (batch > 0 && len > 0) {
+    if (!rows) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+    for (long long b = 0; b < batch; ++b)
+      if (!rows[b]) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+  }
+  return spectrum_frames_host(nullptr, len > 0 ? rows : nullptr, batch, len, sample_rate, fft_size, window, sides,
+                              freq_out, amp_out, phase_out, peak_out, bins_out);
+}
+
+}  // extern "C"
+
+namespace {
+
+int spectrum_frames_host(const double *samples, const double *const *rows, long long batch, long long len,
+                         double sample_rate, long long fft_size, int window, int sides, double *freq_out,
+                         double *amp_out, double *phase_out, pdsp_peak *peak_out, long long *bins_out) {
   if (batch < 0) return fail(PDSP_ERR_BAD_ARG, "batch must be >= 0, got %lld", batch);
-  if (len < 0 || (len > 0 && batch > 0 && !samples)) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+  if (len < 0 || (len > 0 && batch > 0 && !samples && !rows)) return fail(PDSP_ERR_BAD_ARG, "bad samples");
   if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
   // Error order of spectrum.ts:113-132: FFT ctor (power of two) -> createWindow
   // (type; N == 1 returns before the type switch) -> ... -> binFrequencies (rate).
@@ -2299,10 +2336,11 @@ int pdsp_spectrum_batch_host_f64(const double *samples, long long batch, long lo
   static const double kNoSample = 0.0;  // len == 0: every frame is all zero padding
   const double *src = len > 0 ? samples : &kNoSample;
   // findPeak runs on the host over the f64 amplitudes (host_peaks), inside the call's staging loop
-  const int rc_run = f64 ? spectrum_host_t<double>(plan, src, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out)
-                         : spectrum_host_t<float>(plan, src, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out);
+  const int rc_run =
+      f64 ? spectrum_host_t<double>(plan, src, rows, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out)
+          : spectrum_host_t<float>(plan, src, rows, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out);
   trim_stage(plan);
   return rc_run;
 }
 
-}  // extern "C"
+}  // namespace

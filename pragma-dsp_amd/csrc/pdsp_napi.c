@@ -266,6 +266,85 @@ static napi_value SpectrumBatch(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* spectrumRows(frames, start, batch, frameLen, sampleRate, fftSizeOrMinus1, window, sides, freq, amp, phase, peaks)
+ * frames: a JS array whose elements start .. start+batch-1 are Float64Arrays of frameLen samples each -- taken where
+ * they lie (pdsp_spectrum_rows_host_f64), not flattened; outputs as spectrumBatch. */
+static napi_value SpectrumRows(napi_env env, napi_callback_info info) {
+  napi_value argv[12];
+  if (!get_args(env, info, 12, argv)) return NULL;
+  double *freq, *amp, *ph, *pk, rate;
+  size_t nf, na, np, npk;
+  int64_t start, batch, len, fft_size, window, sides;
+  bool is_array = false;
+  uint32_t nframes = 0;
+  if (napi_is_array(env, argv[0], &is_array) != napi_ok || !is_array ||
+      napi_get_array_length(env, argv[0], &nframes) != napi_ok) {
+    napi_throw_type_error(env, NULL, "pdsp_napi: spectrumRows expects an array of Float64Arrays");
+    return NULL;
+  }
+  if (!get_i64(env, argv[1], &start) || !get_i64(env, argv[2], &batch) || !get_i64(env, argv[3], &len) ||
+      !get_f64(env, argv[4], &rate) || !get_i64(env, argv[5], &fft_size) || !get_i64(env, argv[6], &window) ||
+      !get_i64(env, argv[7], &sides) || !f64_array(env, argv[8], &freq, &nf) || !f64_array(env, argv[9], &amp, &na) ||
+      !f64_array(env, argv[10], &ph, &np) || !f64_array(env, argv[11], &pk, &npk))
+    return NULL;
+  if (start < 0 || batch < 0 || len < 0 || start + batch > (int64_t)nframes) {
+    napi_throw_error(env, NULL, "pdsp_napi: spectrumRows frame range out of bounds");
+    return NULL;
+  }
+  const long long n = fft_size >= 0 ? fft_size : pdsp_next_pow2((long long)len);
+  const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
+  if (pdsp_is_pow2(n) && ((long long)nf < bins || (long long)na < batch * bins || (long long)np < batch * bins ||
+                          (long long)npk < 4 * batch)) {
+    napi_throw_error(env, NULL, "pdsp_napi: spectrumRows outputs too small");
+    return NULL;
+  }
+  const double **rows = (const double **)malloc(sizeof(double *) * (size_t)(batch > 0 ? batch : 1));
+  pdsp_peak *recs = (pdsp_peak *)malloc(sizeof(pdsp_peak) * (size_t)(batch > 0 ? batch : 1));
+  if (!rows || !recs) {
+    free(rows);
+    free(recs);
+    napi_throw_error(env, NULL, "pdsp_napi: out of memory");
+    return NULL;
+  }
+  static double dummy = 0.0;
+  for (int64_t b = 0; b < batch; ++b) {
+    napi_handle_scope scope;
+    napi_value el;
+    double *p = NULL;
+    size_t plen = 0;
+    int ok = napi_open_handle_scope(env, &scope) == napi_ok;
+    if (ok) {
+      ok = napi_get_element(env, argv[0], (uint32_t)(start + b), &el) == napi_ok && f64_array(env, el, &p, &plen);
+      if (ok && (int64_t)plen != len) {
+        napi_throw_error(env, NULL, "pdsp_napi: spectrumRows frames must all have frameLen samples");
+        ok = 0;
+      }
+      napi_close_handle_scope(env, scope);
+    } else {
+      napi_throw_error(env, NULL, "pdsp_napi: N-API call failed: napi_open_handle_scope");
+    }
+    if (!ok) {
+      free(rows);
+      free(recs);
+      return NULL;
+    }
+    rows[b] = p ? p : &dummy; /* a zero-length Float64Array has no data pointer */
+  }
+  const int rc = pdsp_spectrum_rows_host_f64(rows, batch, len, rate, fft_size, (int)window, (int)sides, freq, amp, ph, recs,
+                                             NULL);
+  if (rc == PDSP_OK)
+    for (int64_t b = 0; b < batch; ++b) {
+      pk[4 * b + 0] = (double)recs[b].index;
+      pk[4 * b + 1] = recs[b].frequency;
+      pk[4 * b + 2] = recs[b].amplitude;
+      pk[4 * b + 3] = recs[b].phase;
+    }
+  free(rows);
+  free(recs);
+  if (rc != PDSP_OK) return throw_pdsp(env);
+  return NULL;
+}
+
 /* binFrequencies(size, sampleRate, sides, out)   [fourier.ts:147-165] */
 static napi_value BinFrequencies(napi_env env, napi_callback_info info) {
   napi_value argv[4];
@@ -323,7 +402,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"planCreate", PlanCreate}, {"transform", Transform},   {"windowMake", WindowMake},
       {"applyWindow", ApplyWindow}, {"magnitude", Magnitude}, {"phase", Phase},
       {"spectrum", Spectrum},     {"binFrequencies", BinFrequencies}, {"fftShift", FftShift},
-      {"spectrumBatch", SpectrumBatch},
+      {"spectrumBatch", SpectrumBatch}, {"spectrumRows", SpectrumRows},
       {"nextPow2", NextPow2},     {"deviceCount", DeviceCount},
   };
   for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {

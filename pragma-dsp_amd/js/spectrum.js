@@ -60,14 +60,23 @@ function spectrumBatch(frames, options) {
     }
     if (sampleRate <= 0) throw new Error('Sample rate must be positive, got ' + sampleRate);
     const bins = one ? Math.floor(targetSize / 2) + 1 : targetSize;
-    const flat = new Float64Array(batch * len);
-    for (let b = 0; b < batch; b++) flat.set(core._toF64(frames[start + b]), b * len);
     const frequencies = new Float64Array(bins);
     const amplitude = new Float64Array(batch * bins);
     const phase = new Float64Array(batch * bins);
     const peaks = new Float64Array(4 * batch);
-    native.spectrumBatch(flat, batch, len, sampleRate, targetSize, id === undefined ? 0 : id, one ? 0 : 1,
-      frequencies, amplitude, phase, peaks);
+    // a run of Float64Arrays is read where it lies (one pointer per frame); anything else -- plain arrays,
+    // Float32Arrays, holes read as 0 -- is flattened to f64 first
+    let inPlace = true;
+    for (let b = start; b < end && inPlace; b++) inPlace = frames[b] instanceof Float64Array;
+    if (inPlace) {
+      native.spectrumRows(frames, start, batch, len, sampleRate, targetSize, id === undefined ? 0 : id, one ? 0 : 1,
+        frequencies, amplitude, phase, peaks);
+    } else {
+      const flat = new Float64Array(batch * len);
+      for (let b = 0; b < batch; b++) flat.set(core._toF64(frames[start + b]), b * len);
+      native.spectrumBatch(flat, batch, len, sampleRate, targetSize, id === undefined ? 0 : id, one ? 0 : 1,
+        frequencies, amplitude, phase, peaks);
+    }
     for (let b = 0; b < batch; b++) {
       out.push({
         frequencies: b === 0 ? frequencies : frequencies.slice(),

@@ -51,6 +51,45 @@ const results = cases.map((c) => {
         return { same: same, count: rs.length, bins: rs.map((r) => r.amplitude.length),
                  peak0: rs.length ? rs[0].peak : null, empty: p.spectrumBatch([], c.options).length };
       }
+      case 'spectrumBatchTyped': {
+        // frames held as Float64Arrays are read where they lie (native.spectrumRows); `mixed` keeps every third one a
+        // plain array, which sends its run through the flattening path: same results either way
+        const frames = c.frames.map((f, i) => (c.mixed && i % 3 === 1 ? f : Float64Array.from(f)));
+        const rs = p.spectrumBatch(frames, c.options);
+        const plain = p.spectrumBatch(c.frames, c.options);
+        const eq = (a, b) => a.length === b.length && a.every((v, i) => Object.is(v, b[i]) || v === b[i]);
+        let same = rs.length === plain.length;
+        for (let i = 0; same && i < rs.length; i++) {
+          same = eq(rs[i].frequencies, plain[i].frequencies) && eq(rs[i].amplitude, plain[i].amplitude) &&
+            eq(rs[i].phase, plain[i].phase) && rs[i].peak.index === plain[i].peak.index &&
+            rs[i].peak.amplitude === plain[i].peak.amplitude && rs[i].peak.phase === plain[i].peak.phase;
+        }
+        return { same: same, count: rs.length };
+      }
+      case 'spectrumBatchBig': {
+        // enough frames for the library to cut the call into chunks on several workers: every sampled result must
+        // still equal the one-frame spectrum() exactly, from Float64Array frames and from plain arrays
+        let seed = 12345;
+        const rnd = () => { seed = (seed * 1103515245 + 12345) % 2147483648; return seed / 2147483648 - 0.5; };
+        const frames = [];
+        for (let b = 0; b < c.count; b++) {
+          const f = new Float64Array(c.n);
+          const k = 3 + (b % 97);
+          for (let i = 0; i < c.n; i++) f[i] = Math.sin(2 * Math.PI * k * i / c.n) + 0.1 * rnd();
+          frames.push(f);
+        }
+        const eq = (a, b) => a.length === b.length && a.every((v, i) => Object.is(v, b[i]) || v === b[i]);
+        const rs = p.spectrumBatch(frames, c.options);
+        const plain = p.spectrumBatch(frames.map((f) => Array.from(f)), c.options);
+        let same = rs.length === c.count && plain.length === c.count;
+        const step = Math.max(1, Math.floor(c.count / 23));
+        for (let i = 0; same && i < c.count; i += (i + step < c.count || i === c.count - 1 ? step : c.count - 1 - i)) {
+          const one = p.spectrum(frames[i], c.options);
+          same = eq(rs[i].amplitude, one.amplitude) && eq(rs[i].phase, one.phase) && rs[i].peak.index === one.peak.index &&
+            eq(plain[i].amplitude, one.amplitude) && eq(plain[i].phase, one.phase) && plain[i].peak.index === one.peak.index;
+        }
+        return { same: same, count: rs.length, lastPeak: rs[c.count - 1].peak.index };
+      }
       case 'spectrumBatchFull':
         // every result in full, for a direct comparison with the CPU oracle on the Python side
         return p.spectrumBatch(c.frames, c.options).map((r) => ({

@@ -144,3 +144,31 @@ def test_chunked_calls_from_two_threads(capi, oracle_mod):
     for w, g in zip(want, got):
         for a, b in zip(w, g):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("n,length,batch", [(1024, 1024, 1501), (4096, 3000, 40), (8, 8, 3)])
+def test_rows_variant_equals_contiguous_frames(capi, precision, n, length, batch):
+    """pdsp_spectrum_rows_host_f64 (one pointer per frame: an array of Float64Arrays taken where it lies) against
+    pdsp_spectrum_batch_host_f64 on the same frames flattened: identical, chunked or not."""
+    capi.lib.pdsp_set_host_precision(precision)
+    rng = np.random.default_rng(5 + n)
+    frames = [rng.standard_normal(length) for _ in range(batch)]     # separately allocated rows
+    x = np.stack(frames)
+    for threads in (1, 4):
+        want = _spectrum_batch(capi, x, n, 1, 0, threads)
+        bins = n // 2 + 1
+        freq, amp, ph = np.full(bins, np.nan), np.full((batch, bins), np.nan), np.full((batch, bins), np.nan)
+        peaks = (capi.Peak * batch)()
+        dp = C.POINTER(C.c_double)
+        rows = (dp * batch)(*[capi.dptr(f) for f in frames])
+        capi.check(capi.lib.pdsp_spectrum_rows_host_f64(rows, batch, length, 48000.0, n, 1, 0, capi.dptr(freq), capi.dptr(amp),
+                                                        capi.dptr(ph), peaks, None))
+        pk = np.array([(p.index, p.frequency, p.amplitude, p.phase) for p in peaks])
+        for a, b in zip(want, (freq, amp, ph, pk)):
+            assert np.array_equal(a, b)
+    # a null row is refused before any device work
+    rows[batch // 2] = None
+    rc = capi.lib.pdsp_spectrum_rows_host_f64(rows, batch, length, 48000.0, n, 1, 0, capi.dptr(freq), capi.dptr(amp),
+                                              capi.dptr(ph), peaks, None)
+    assert rc == capi.ERR_BAD_ARG

@@ -92,6 +92,13 @@ def test_js_dropin_parity(tmp_path, oracle_mod, reallife, manifest):
                    {"op": "spectrumBatch", "frames": frames[:5],
                     "options": {"sampleRate": 48000, "fftSize": 2048, "sides": "two", "window": "blackman"}}]
     batch_cases += [dict(c, op="spectrumBatchFull") for c in batch_cases]
+    # frames held as Float64Arrays (read in place through pdsp_spectrum_rows_host_f64), a mixed run, and a call large
+    # enough to be cut into chunks on the library's workers (600 frames of 4096 samples, last frame's tone at bin 20)
+    typed_cases = [dict(batch_cases[0], op="spectrumBatchTyped"), dict(batch_cases[1], op="spectrumBatchTyped", mixed=True),
+                   {"op": "spectrumBatchBig", "n": 4096, "count": 600, "options": {"sampleRate": 48000, "window": "hann"}}]
+    tres = run_cases(typed_cases, tmp_path)
+    assert tres[0] == {"same": True, "count": 9} and tres[1] == {"same": True, "count": 5}
+    assert tres[2] == {"same": True, "count": 600, "lastPeak": 3 + 599 % 97}
     bres = run_cases(batch_cases, tmp_path)
     assert bres[0]["same"] is True and bres[0]["count"] == 9 and bres[0]["empty"] == 0
     assert bres[0]["bins"] == [513] * 5 + [257] * 3 + [5] and bres[0]["peak0"]["index"] == 8
@@ -227,5 +234,9 @@ def test_napi_addon_argument_handling_under_address_sanitizer(tmp_path):
     for name in ("windowMake short out", "binFrequencies short out", "fftShift short out", "magnitude short out",
                  "phase mismatched planes", "spectrum short out", "spectrumBatch short out", "transform wrong types",
                  "wrong argument count", "planCreate 0", "planCreate -8", "windowMake bad type", "binFrequencies rate 0",
-                 "spectrum bad size"):
+                 "spectrum bad size", "spectrumRows not an array", "spectrumRows range past the end",
+                 "spectrumRows negative start", "spectrumRows ragged frame", "spectrumRows plain-array frame",
+                 "spectrumRows hole", "spectrumRows short out", "spectrumRows bad size", "spectrumRows bad rate"):
         assert log[name][0] == "throws", (name, log[name])
+    assert log["spectrumRows bad size"] == ("throws", "FFT size must be power of two, got 12")
+    assert log["spectrumRows bad rate"] == ("throws", "Sample rate must be positive, got 0")
