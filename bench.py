@@ -293,22 +293,28 @@ def stream_throughput(args, dev) -> int:
     return 0
 
 
-def host_batch_throughput(args, dev) -> int:
+def host_batch_rows(sizes=(1024, 4096, 16384), precisions=(64, 32), log2_samples=26, reps=4) -> list:
     """The batched host boundary itself (what the JS drop-in's spectrumBatch() binds): f64 frames in host memory ->
-    pdsp_spectrum_batch_host_f64 -> f64 amplitude / phase rows + SpectrumPeak records in host memory, 2^26 samples per
-    call.  Large calls are cut into chunks on several workers inside the library (staging, both PCIe directions and
-    the kernels overlap); PDSP_HOST_THREADS=1 is the one-shot sequence of rounds 1-3, timed beside it.  PCIe- and
-    host-bound: DESIGN.md's PCIe-inclusive note, never `value` of the headline metric.  16 rows per case against
-    the oracle's spectrum()."""
-    import ctypes as C
+    pdsp_spectrum_batch_host_f64 -> f64 amplitude / phase rows + SpectrumPeak records in host memory, 2^log2_samples
+    samples per call.  Large calls are cut into chunks on several workers inside the library (staging, both PCIe
+    directions and the kernels overlap); PDSP_HOST_THREADS=1 is the one-shot sequence of rounds 1-3, timed beside it.
+    PCIe- and host-bound: DESIGN.md's PCIe-inclusive note, never `value` of the headline metric.  16 rows per case
+    against the oracle's spectrum()."""
     import oracle
     import pragma_dsp_amd as pd
     from pragma_dsp_amd._capi import Peak, check, dptr
     lib = pd.lib
     rows = []
     env0 = os.environ.get("PDSP_HOST_THREADS")
-    for n in (1024, 4096, 16384):
-        batch = (1 << 26) // n
+
+    def restore_env():
+        if env0 is None:
+            os.environ.pop("PDSP_HOST_THREADS", None)
+        else:
+            os.environ["PDSP_HOST_THREADS"] = env0
+
+    for n in sizes:
+        batch = (1 << log2_samples) // n
         rng = np.random.default_rng(n)
         x = rng.standard_normal((batch, n)) + np.sin(2 * np.pi * 37 * np.arange(n) / n)
         bins = n // 2 + 1
@@ -316,16 +322,16 @@ def host_batch_throughput(args, dev) -> int:
         peaks = (Peak * batch)()
         pick = np.linspace(0, batch - 1, 16).astype(int)
         want = [oracle.spectrum(x[r], sample_rate=48000.0, fft_size=n, window="hann") for r in pick]
-        for bits in (64, 32):
+        for bits in precisions:
             prev = lib.pdsp_set_host_precision(bits)
             try:
                 for threads in (None, "1"):
                     if threads is None:
-                        os.environ.pop("PDSP_HOST_THREADS", None) if env0 is None else os.environ.__setitem__("PDSP_HOST_THREADS", env0)
+                        restore_env()
                     else:
                         os.environ["PDSP_HOST_THREADS"] = threads
                     best = None
-                    for _ in range(4):
+                    for _ in range(reps if threads is None else max(2, reps // 2)):
                         t0 = time.perf_counter()
                         check(lib.pdsp_spectrum_batch_host_f64(dptr(x), batch, n, 48000.0, n, 1, 0, dptr(freq), dptr(amp),
                                                                dptr(ph), peaks, None))
@@ -333,18 +339,20 @@ def host_batch_throughput(args, dev) -> int:
                         best = sec if best is None else min(best, sec)
                     err = max(float(np.abs(amp[r] - w["amplitude"]).max() / w["amplitude"].max()) for r, w in zip(pick, want))
                     peaks_ok = all(peaks[int(r)].index == w["peak"]["index"] for r, w in zip(pick, want))
+                    tol = 1e-12 if bits == 64 else 1e-5
                     rows.append({"n": n, "batch": batch, "precision": bits,
                                  "mode": "chunked on the library's workers" if threads is None else "one-shot sequence (PDSP_HOST_THREADS=1)",
                                  "ms": best * 1e3, "GSample_per_s": batch * n / best / 1e9,
                                  "host_GBps_in_plus_out": (x.nbytes + amp.nbytes + ph.nbytes) / best / 1e9,
-                                 "max_rel_err_16_rows": err, "tolerance": 1e-12 if bits == 64 else 1e-5,
-                                 "ok": bool(err <= (1e-12 if bits == 64 else 1e-5) and peaks_ok)})
+                                 "max_rel_err_16_rows": err, "tolerance": tol, "ok": bool(err <= tol and peaks_ok)})
             finally:
                 lib.pdsp_set_host_precision(prev)
-                if env0 is None:
-                    os.environ.pop("PDSP_HOST_THREADS", None)
-                else:
-                    os.environ["PDSP_HOST_THREADS"] = env0
+                restore_env()
+    return rows
+
+
+def host_batch_throughput(args, dev) -> int:
+    rows = host_batch_rows()
     print(json.dumps({"metric": "pdsp_spectrum_batch_host_f64 host-to-host throughput (PCIe-inclusive)", "unit": "GSample/s",
                       "higher_is_better": True, "value": max(r["GSample_per_s"] for r in rows), "n_gpus": 1, "steps": 4,
                       "warmup": 0, "dtype": "f64/f32", "data": "synthetic",
@@ -921,6 +929,14 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                                                                "kernel_back_to_back_us", "js_dropin_latency")}
             except Exception as exc:  # noqa: BLE001
                 out["also"]["single1024"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            try:  # the PCIe-inclusive rate of the batched host boundary (a reported extra, never `value`)
+                hb = host_batch_rows(sizes=(4096,), precisions=(64,), log2_samples=25, reps=3)
+                out["also"]["hostbatch4096"] = {
+                    "config": {"workload": "N=4096 x 8192 host f64 frames -> pdsp_spectrum_batch_host_f64 (hann, one-sided) -> "
+                                           "host f64 amplitude + phase rows + peak records; PCIe-inclusive, never `value`"},
+                    "unit": "GSample/s", "host_cpus": os.cpu_count(), "rows": hb}
+            except Exception as exc:  # noqa: BLE001
+                out["also"]["hostbatch4096"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             rows = 2048
             sel = torch.cat([torch.arange(0, rows // 2), torch.arange(per_gpu // 2, per_gpu // 2 + rows // 2)]) \
@@ -1071,6 +1087,8 @@ def parity_failures(out) -> list:
     for leg, res in (out.get("also") or {}).items():
         if "parity" in res and not res["parity"]["ok"]:
             bad.append(f"also.{leg}.parity")
+        if any(not r.get("ok", True) for r in res.get("rows", []) if isinstance(r, dict)):
+            bad.append(f"also.{leg}.rows")
     return bad
 
 
