@@ -2,7 +2,7 @@
 import * as coreNs from './core';
 import * as fourierNs from './fourier';
 
-export { spectrum, spectrumBatch, SpectrumOptions, SpectrumPeak, SpectrumResult } from './spectrum';
+export { spectrum, spectrumBatch, spectrumStream, SpectrumOptions, SpectrumPeak, SpectrumResult } from './spectrum';
 export { ComplexArray } from './core';
 export { WindowType } from './fourier';
 

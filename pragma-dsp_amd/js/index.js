@@ -10,6 +10,7 @@ const s = require('./spectrum');
 module.exports = {
   spectrum: s.spectrum,
   spectrumBatch: s.spectrumBatch,  // extension: spectrumStream's map as one device batch
+  spectrumStream: s.spectrumStream,  // extension: the same, frame at a time over any iterable (batched inside)
   core: {
     createComplexArray: core.createComplexArray,
     isPowerOfTwo: core.isPowerOfTwo,

@@ -26,3 +26,8 @@ export function spectrum(samples: ArrayLike<number>, options?: SpectrumOptions):
 /** Extension: the map of the reference's spectrumStream (src/effect/index.ts:190-194) as one device batch per
  *  run of equal-length frames; result i equals spectrum(frames[i], options) exactly. */
 export function spectrumBatch(frames: ReadonlyArray<ArrayLike<number>>, options?: SpectrumOptions): SpectrumResult[];
+
+/** Extension: spectrumStream's frame-at-a-time contract (src/effect/index.ts:190-194; one result per frame, in
+ *  order) as a synchronous generator that runs the frames as device batches of `batchFrames` (default 256). */
+export function spectrumStream(frames: Iterable<ArrayLike<number>>, options?: SpectrumOptions,
+  batchFrames?: number): Generator<SpectrumResult, void, undefined>;

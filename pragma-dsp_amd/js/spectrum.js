@@ -90,4 +90,27 @@ function spectrumBatch(frames, options) {
   return out;
 }
 
-module.exports = { spectrum, spectrumBatch };
+// spectrumStream(frames, options, batchFrames): the frame-at-a-time contract of the reference's only streaming
+// caller (src/effect/index.ts:190-194: `Stream.map(frames, spectrum)` -- one result per frame, in input order; an
+// empty input yields nothing, test/reallife/effect.test.ts:136-146) as a synchronous generator over any iterable
+// of frames.  Frames are gathered into batches of `batchFrames` (default 256) and each batch is one spectrumBatch()
+// call -- one device batch per run of equal lengths, plans and windows cached by the engine (the Map<size, FFT> /
+// Map<"type:size", window> of FourierLive, index.ts:30-48) -- so a result is yielded at most batchFrames frames
+// after its input was drawn.  Each frame is copied when it is drawn (a producer may refill one buffer per frame).
+function* spectrumStream(frames, options, batchFrames) {
+  const limit = batchFrames === undefined || batchFrames === null ? 256 : batchFrames;
+  if (!(limit >= 1)) throw new Error('batchFrames must be >= 1, got ' + limit);
+  let pending = [];
+  for (const f of frames) {
+    const x = core._toF64(f);
+    pending.push(x === f ? x.slice() : x);  // _toF64 already made a fresh array unless f is a Float64Array
+    if (pending.length >= limit) {
+      const out = spectrumBatch(pending, options);
+      pending = [];
+      yield* out;
+    }
+  }
+  if (pending.length) yield* spectrumBatch(pending, options);
+}
+
+module.exports = { spectrum, spectrumBatch, spectrumStream };

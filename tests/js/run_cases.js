@@ -90,6 +90,31 @@ const results = cases.map((c) => {
         }
         return { same: same, count: rs.length, lastPeak: rs[c.count - 1].peak.index };
       }
+      case 'spectrumStream': {
+        // a producer that refills ONE buffer per frame (frames are copied when drawn), batches of c.batchFrames:
+        // result i must equal spectrum(frames[i], options) exactly, in order; an empty iterable yields nothing
+        const eq = (a, b) => a.length === b.length && a.every((v, i) => Object.is(v, b[i]) || v === b[i]);
+        let drawn = 0;
+        const yieldedAfter = [];
+        function* producer() {
+          const buf = new Float64Array(c.frames[0].length);
+          for (const f of c.frames) {
+            if (f.length === buf.length) { buf.set(f); drawn++; yield buf; } else { drawn++; yield f; }
+          }
+        }
+        let same = true, count = 0;
+        for (const r of p.spectrumStream(producer(), c.options, c.batchFrames)) {
+          const one = p.spectrum(c.frames[count], c.options);
+          same = same && eq(r.amplitude, one.amplitude) && eq(r.phase, one.phase) && eq(r.frequencies, one.frequencies) &&
+            r.peak.index === one.peak.index && r.peak.amplitude === one.peak.amplitude;
+          yieldedAfter.push(drawn);
+          count++;
+        }
+        let threw = null;
+        try { Array.from(p.spectrumStream(c.frames, c.options, 0)); } catch (e) { threw = e.message; }
+        return { same: same, count: count, yieldedAfter: yieldedAfter,
+                 empty: Array.from(p.spectrumStream([], c.options)).length, threw: threw };
+      }
       case 'spectrumBatchFull':
         // every result in full, for a direct comparison with the CPU oracle on the Python side
         return p.spectrumBatch(c.frames, c.options).map((r) => ({

@@ -44,7 +44,7 @@ def test_js_exports_and_error_texts(tmp_path):
     cases = [{"op": "exports"}, {"op": "misc"}, {"op": "createWindow", "type": "blackman", "size": 64}]
     cases += [{"op": "throws", "what": w} for w in throws]
     res = run_cases(cases, tmp_path)
-    assert res[0]["root"] == ["spectrum", "spectrumBatch", "core", "fourier"]
+    assert res[0]["root"] == ["spectrum", "spectrumBatch", "spectrumStream", "core", "fourier"]
     assert res[0]["core"] == ["createComplexArray", "isPowerOfTwo", "nextPowerOfTwo", "Radix2Fft"]
     assert res[0]["fourier"] == ["createWindow", "applyWindow", "FFT", "magnitude", "phase", "fftShift",
                                  "fftShiftComplex", "binFrequencies"]
@@ -96,9 +96,15 @@ def test_js_dropin_parity(tmp_path, oracle_mod, reallife, manifest):
     # enough to be cut into chunks on the library's workers (600 frames of 4096 samples, last frame's tone at bin 20)
     typed_cases = [dict(batch_cases[0], op="spectrumBatchTyped"), dict(batch_cases[1], op="spectrumBatchTyped", mixed=True),
                    {"op": "spectrumBatchBig", "n": 4096, "count": 600, "options": {"sampleRate": 48000, "window": "hann"}}]
+    # spectrumStream: the frame-at-a-time contract (src/effect/index.ts:190-194) over an iterable whose producer
+    # refills one buffer, batches of 4: nine results in order, yielded once their batch (4, 8, 9 frames drawn) ran
+    typed_cases.append({"op": "spectrumStream", "frames": frames, "batchFrames": 4,
+                        "options": {"sampleRate": 48000, "window": "hann"}})
     tres = run_cases(typed_cases, tmp_path)
     assert tres[0] == {"same": True, "count": 9} and tres[1] == {"same": True, "count": 5}
     assert tres[2] == {"same": True, "count": 600, "lastPeak": 3 + 599 % 97}
+    assert tres[3] == {"same": True, "count": 9, "yieldedAfter": [4] * 4 + [8] * 4 + [9], "empty": 0,
+                       "threw": "batchFrames must be >= 1, got 0"}
     bres = run_cases(batch_cases, tmp_path)
     assert bres[0]["same"] is True and bres[0]["count"] == 9 and bres[0]["empty"] == 0
     assert bres[0]["bins"] == [513] * 5 + [257] * 3 + [5] and bres[0]["peak0"]["index"] == 8

@@ -25,7 +25,7 @@ def test_declarations_match_runtime_exports():
     for mod in ("core", "fourier", "spectrum"):
         assert _declared(mod) == _runtime_exports(mod), mod
     idx = open(os.path.join(JS, "index.d.ts")).read()
-    for name in ("spectrum", "spectrumBatch", "core", "fourier", "Radix2Fft", "FFT", "createWindow", "applyWindow",
+    for name in ("spectrum", "spectrumBatch", "spectrumStream", "core", "fourier", "Radix2Fft", "FFT", "createWindow", "applyWindow",
                  "magnitude", "phase", "fftShift", "fftShiftComplex", "binFrequencies", "createComplexArray",
                  "isPowerOfTwo", "nextPowerOfTwo"):
         assert re.search(r"\b%s\b" % name, idx), name
