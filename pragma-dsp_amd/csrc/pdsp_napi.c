@@ -131,6 +131,41 @@ static napi_value Transform(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* transformBatch(plan, batch, re, imOrNull, outRe, outIm, inverse): `batch` rows of the plan's size, planes of
+ * batch*size values   [Radix2Fft.transform row by row, fft.ts:89-151; the loop of bench/reallife/signals.ts:264-270
+ * as one call] */
+static napi_value TransformBatch(napi_env env, napi_callback_info info) {
+  napi_value argv[7];
+  if (!get_args(env, info, 7, argv)) return NULL;
+  void *plan = NULL;
+  NAPI_OK_OR_THROW(env, napi_get_value_external(env, argv[0], &plan));
+  int64_t batch;
+  double *re, *im, *ore, *oim;
+  size_t nre, nim, nore, noim;
+  if (!get_i64(env, argv[1], &batch) || !f64_array(env, argv[2], &re, &nre) || !f64_array(env, argv[3], &im, &nim) ||
+      !f64_array(env, argv[4], &ore, &nore) || !f64_array(env, argv[5], &oim, &noim))
+    return NULL;
+  bool inverse = false;
+  NAPI_OK_OR_THROW(env, napi_get_value_bool(env, argv[6], &inverse));
+  const long long n = pdsp_plan_size((pdsp_plan *)plan);
+  if (batch < 0 || n <= 0 || batch > (int64_t)(((size_t)-1) / 16 / (size_t)n)) {
+    napi_throw_error(env, NULL, "pdsp_napi: transformBatch bad batch");
+    return NULL;
+  }
+  const size_t want = (size_t)batch * (size_t)n;
+  if (nre != want || (im && nim != want) || nore != want || noim != want) {
+    napi_throw_error(env, NULL, "pdsp_napi: transformBatch planes must hold batch * size values");
+    return NULL;
+  }
+  if (inverse && !im && batch > 0) {
+    napi_throw_error(env, NULL, "pdsp_napi: transformBatch inverse needs an imaginary plane");
+    return NULL;
+  }
+  if (pdsp_fft_transform_host_f64((pdsp_plan *)plan, batch, n, re, im, ore, oim, inverse ? 1 : 0) != PDSP_OK)
+    return throw_pdsp(env);
+  return NULL;
+}
+
 /* windowMake(type, size, out)   [createWindow, fourier.ts:14-52] */
 static napi_value WindowMake(napi_env env, napi_callback_info info) {
   napi_value argv[3];
@@ -400,6 +435,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     napi_callback fn;
   } fns[] = {
       {"planCreate", PlanCreate}, {"transform", Transform},   {"windowMake", WindowMake},
+      {"transformBatch", TransformBatch},
       {"applyWindow", ApplyWindow}, {"magnitude", Magnitude}, {"phase", Phase},
       {"spectrum", Spectrum},     {"binFrequencies", BinFrequencies}, {"fftShift", FftShift},
       {"spectrumBatch", SpectrumBatch}, {"spectrumRows", SpectrumRows},

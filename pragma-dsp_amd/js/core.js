@@ -60,6 +60,47 @@ class Radix2Fft {
     return this._transform(input.real, input.imag, out, true);
   }
 
+  // Extensions: the same three transforms on MANY rows in one call -- the loop of the reference's batch idiom
+  // (bench/reallife/signals.ts:264-270: `for (...) fft.forward(input)`) as one device batch.  Element i of the
+  // result equals forward(inputs[i]) / forwardComplex(inputs[i]) / inverse(inputs[i]); the ComplexArrays of a
+  // batch are views into one buffer per plane.  Length checks and messages are those of fft.ts:95-104, per row.
+  forwardBatch(inputs) {
+    return this._transformBatch(inputs, false, false);
+  }
+
+  forwardComplexBatch(inputs) {
+    return this._transformBatch(inputs, true, false);
+  }
+
+  inverseBatch(inputs) {
+    return this._transformBatch(inputs, true, true);
+  }
+
+  _transformBatch(inputs, complex, inverse) {
+    const batch = inputs.length >>> 0;
+    const n = this.size;
+    const re = new Float64Array(batch * n);
+    const im = complex ? new Float64Array(batch * n) : null;
+    for (let b = 0; b < batch; b += 1) {
+      const r = complex ? inputs[b].real : inputs[b];
+      const i = complex ? inputs[b].imag : null;
+      if (r.length !== n) throw new Error('FFT input length ' + r.length + ' != size ' + n);
+      if (i && i.length !== n) throw new Error('FFT input length ' + i.length + ' != size ' + n);
+      re.set(toF64(r), b * n);
+      if (im) {
+        if (i) im.set(toF64(i), b * n);
+      }
+    }
+    const ore = new Float64Array(batch * n);
+    const oim = new Float64Array(batch * n);
+    if (batch > 0) native.transformBatch(this._plan, batch, re, im, ore, oim, inverse);
+    const out = new Array(batch);
+    for (let b = 0; b < batch; b += 1) {
+      out[b] = { real: ore.subarray(b * n, (b + 1) * n), imag: oim.subarray(b * n, (b + 1) * n) };
+    }
+    return out;
+  }
+
   _transform(inputReal, inputImag, out, inverse) {
     if (inputReal.length !== this.size) {
       throw new Error('FFT input length ' + inputReal.length + ' != size ' + this.size);

@@ -15,6 +15,11 @@ export class FFT {
   forward(input: ArrayLike<number>, out?: ComplexArray): ComplexArray;
   forwardComplex(input: ComplexArray, out?: ComplexArray): ComplexArray;
   inverse(input: ComplexArray, out?: ComplexArray): ComplexArray;
+  /** Extensions: element i equals forward / forwardComplex / inverse of inputs[i]; one device batch per call
+   *  (the loop of bench/reallife/signals.ts:264-270), results are views into one buffer per plane. */
+  forwardBatch(inputs: ReadonlyArray<ArrayLike<number>>): ComplexArray[];
+  forwardComplexBatch(inputs: ReadonlyArray<ComplexArray>): ComplexArray[];
+  inverseBatch(inputs: ReadonlyArray<ComplexArray>): ComplexArray[];
   createComplexArray(fill?: number): ComplexArray;
 }
 

@@ -50,6 +50,10 @@ class FFT {
   forward(input, out) { return this._kernel.forward(input, out); }
   forwardComplex(input, out) { return this._kernel.forwardComplex(input, out); }
   inverse(input, out) { return this._kernel.inverse(input, out); }
+  // extensions (see Radix2Fft): many rows in one device batch
+  forwardBatch(inputs) { return this._kernel.forwardBatch(inputs); }
+  forwardComplexBatch(inputs) { return this._kernel.forwardComplexBatch(inputs); }
+  inverseBatch(inputs) { return this._kernel.inverseBatch(inputs); }
   createComplexArray(fill) { return core.createComplexArray(this.size, fill === undefined ? 0 : fill); }
 }
 

@@ -90,6 +90,36 @@ const results = cases.map((c) => {
         }
         return { same: same, count: rs.length, lastPeak: rs[c.count - 1].peak.index };
       }
+      case 'transformBatch': {
+        // forwardBatch / forwardComplexBatch / inverseBatch: element i equals the one-row call on inputs[i] exactly
+        // (c.n <= 8192: the kernel does not depend on the row count), also when the call is large enough to be cut
+        // into chunks on the library's workers (c.count rows generated here)
+        const fft = new p.fourier.FFT(c.n);
+        let seed = 4242;
+        const rnd = () => { seed = (seed * 1103515245 + 12345) % 2147483648; return seed / 2147483648 - 0.5; };
+        const rows = [];
+        for (let b = 0; b < c.count; b++) { const f = new Float64Array(c.n); for (let i = 0; i < c.n; i++) f[i] = rnd(); rows.push(f); }
+        const eq = (a, b) => a.length === b.length && a.every((v, i) => Object.is(v, b[i]) || v === b[i]);
+        const fwd = fft.forwardBatch(rows);
+        const pick = [0, 1, Math.floor(c.count / 2), c.count - 1];
+        let same = fwd.length === c.count;
+        for (const i of pick) { const one = fft.forward(rows[i]); same = same && eq(fwd[i].real, one.real) && eq(fwd[i].imag, one.imag); }
+        const cplx = rows.map((r, i) => ({ real: r, imag: rows[(i + 1) % c.count] }));
+        const fc = fft.forwardComplexBatch(cplx);
+        for (const i of pick) { const one = fft.forwardComplex(cplx[i]); same = same && eq(fc[i].real, one.real) && eq(fc[i].imag, one.imag); }
+        const back = fft.inverseBatch(fc);
+        let worst = 0;
+        for (const i of pick) {
+          const one = fft.inverse(fc[i]);
+          same = same && eq(back[i].real, one.real) && eq(back[i].imag, one.imag);
+          for (let k = 0; k < c.n; k++) worst = Math.max(worst, Math.abs(back[i].real[k] - cplx[i].real[k]), Math.abs(back[i].imag[k] - cplx[i].imag[k]));
+        }
+        let threw = null;
+        try { fft.forwardBatch([rows[0], new Float64Array(3)]); } catch (e) { threw = e.message; }
+        const plain = new p.core.Radix2Fft(8).forwardBatch([[0, 1, 0, -1, 0, 1, 0, -1], [1, , 1, 1, 1, 1, 1, 1]]);
+        return { same: same, count: fwd.length, roundTrip: worst, threw: threw, empty: fft.forwardBatch([]).length,
+                 sineBin2: arr(plain[0].imag), hole: arr(plain[1].real) };
+      }
       case 'spectrumStream': {
         // a producer that refills ONE buffer per frame (frames are copied when drawn), batches of c.batchFrames:
         // result i must equal spectrum(frames[i], options) exactly, in order; an empty iterable yields nothing

@@ -100,7 +100,16 @@ def test_js_dropin_parity(tmp_path, oracle_mod, reallife, manifest):
     # refills one buffer, batches of 4: nine results in order, yielded once their batch (4, 8, 9 frames drawn) ran
     typed_cases.append({"op": "spectrumStream", "frames": frames, "batchFrames": 4,
                         "options": {"sampleRate": 48000, "window": "hann"}})
+    # FFT.forwardBatch / forwardComplexBatch / inverseBatch (the reference's batch loop, bench/reallife/signals.ts:264-270,
+    # as one device batch): a small call and one large enough for the library's chunked path (300 rows of 8192)
+    typed_cases += [{"op": "transformBatch", "n": 1024, "count": 9}, {"op": "transformBatch", "n": 8192, "count": 300}]
     tres = run_cases(typed_cases, tmp_path)
+    for tb in tres[4:6]:
+        assert tb["same"] is True and tb["roundTrip"] < 1e-12 and tb["empty"] == 0
+        assert tb["threw"] == "FFT input length 3 != size " + str(1024 if tb["count"] == 9 else 8192)
+        assert np.allclose(tb["sineBin2"], [0, 0, -4, 0, 0, 0, 4, 0], atol=1e-12)       # the README's N = 8 sine
+        assert np.allclose(tb["hole"], np.fft.fft([1, 0, 1, 1, 1, 1, 1, 1]).real, atol=1e-12)  # a hole reads as 0 (`?? 0`)
+    assert [tb["count"] for tb in tres[4:6]] == [9, 300]
     assert tres[0] == {"same": True, "count": 9} and tres[1] == {"same": True, "count": 5}
     assert tres[2] == {"same": True, "count": 600, "lastPeak": 3 + 599 % 97}
     assert tres[3] == {"same": True, "count": 9, "yieldedAfter": [4] * 4 + [8] * 4 + [9], "empty": 0,
@@ -242,7 +251,8 @@ def test_napi_addon_argument_handling_under_address_sanitizer(tmp_path):
                  "wrong argument count", "planCreate 0", "planCreate -8", "windowMake bad type", "binFrequencies rate 0",
                  "spectrum bad size", "spectrumRows not an array", "spectrumRows range past the end",
                  "spectrumRows negative start", "spectrumRows ragged frame", "spectrumRows plain-array frame",
-                 "spectrumRows hole", "spectrumRows short out", "spectrumRows bad size", "spectrumRows bad rate"):
+                 "spectrumRows hole", "spectrumRows short out", "spectrumRows bad size", "spectrumRows bad rate",
+                 "transformBatch wrong plan"):
         assert log[name][0] == "throws", (name, log[name])
     assert log["spectrumRows bad size"] == ("throws", "FFT size must be power of two, got 12")
     assert log["spectrumRows bad rate"] == ("throws", "Sample rate must be positive, got 0")
