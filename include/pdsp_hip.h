@@ -281,6 +281,12 @@ PDSP_API int pdsp_spectrum_f64(const pdsp_plan *plan, long long batch,
 PDSP_API int pdsp_fft_transform_host_f64(pdsp_plan *plan, long long batch, long long in_len,
                                          const double *re_in, const double *im_in,
                                          double *re_out, double *im_out, int inverse);
+/* The same with one pointer per input row (re_rows[b], and im_rows[b] unless im_rows is NULL, point at N values
+ * each, anywhere in host memory): a JS array of Float64Arrays / ComplexArrays taken where it lies.  Outputs are
+ * contiguous planes of batch*N values as above. */
+PDSP_API int pdsp_fft_transform_rows_host_f64(pdsp_plan *plan, long long batch, long long in_len,
+                                              const double *const *re_rows, const double *const *im_rows,
+                                              double *re_out, double *im_out, int inverse);
 /* applyWindow / magnitude / phase on host arrays (fourier.ts:54-67, :98-120).
  * Small inputs: done by launching the same device kernels. */
 PDSP_API int pdsp_apply_window_host_f64(const double *in, long long in_len, const double *window,

@@ -108,6 +108,7 @@ def _load() -> C.CDLL:
         "pdsp_spectrum_f64": ([vp, ll, vp, ll, ll, vp, i32, vp, vp, vp, vp], i32),
         "pdsp_spectrum_peaks_f32": ([vp, ll, vp, ll, ll, vp, i32, dbl, vp, vp, vp, vp], i32),
         "pdsp_fft_transform_host_f64": ([vp, ll, ll, dp, dp, dp, dp, i32], i32),
+        "pdsp_fft_transform_rows_host_f64": ([vp, ll, ll, C.POINTER(dp), C.POINTER(dp), dp, dp, i32], i32),
         "pdsp_apply_window_host_f64": ([dp, ll, dp, ll, dp], i32),
         "pdsp_magnitude_host_f64": ([dp, dp, ll, dp], i32),
         "pdsp_phase_host_f64": ([dp, dp, ll, dp], i32),

@@ -1690,35 +1690,55 @@ inline void stage_to_rows(double *dst, const T *src, size_t count) {
     for (size_t i = 0; i < count; ++i) dst[i] = (double)src[i];
 }
 
-// Radix2Fft.transform for `batch` host rows in precision T (f64 at the boundary either way).
+// Radix2Fft.transform for `batch` host rows in precision T (f64 at the boundary either way).  Input rows either
+// contiguous (re_in / im_in) or one pointer per row (re_rows / im_rows: pdsp_fft_transform_rows_host_f64).
 template <typename T>
-int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const double *im_in, double *re_out,
-                   double *im_out, int inverse) {
-  const size_t cnt = (size_t)batch * (size_t)plan->n;
+int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const double *im_in,
+                   const double *const *re_rows, const double *const *im_rows, double *re_out, double *im_out,
+                   int inverse) {
+  const size_t n = (size_t)plan->n, cnt = (size_t)batch * n;
+  const bool has_im = im_in || im_rows;
+  auto re_row = [&](long long r) { return re_rows ? re_rows[r] : re_in + (size_t)r * n; };
+  auto im_row = [&](long long r) { return im_rows ? im_rows[r] : im_in + (size_t)r * n; };
+  // rows [first, first + count) into staging planes of `count` rows each
+  auto stage_in = [&](T *h_re, T *h_im, long long first, long long count) {
+    if (!re_rows) rows_to_stage<T>(h_re, re_in + (size_t)first * n, (size_t)count * n);
+    else
+      for (long long r = 0; r < count; ++r) rows_to_stage<T>(h_re + (size_t)r * n, re_rows[first + r], n);
+    if (!has_im) return;
+    if (!im_rows) rows_to_stage<T>(h_im, im_in + (size_t)first * n, (size_t)count * n);
+    else
+      for (long long r = 0; r < count; ++r) rows_to_stage<T>(h_im + (size_t)r * n, im_rows[first + r], n);
+  };
   {
     // many rows: chunks on several workers (run_chunked); planes that overlap each other in host memory keep the
     // one-shot sequence, which has read every input before it writes any output
-    const size_t row_bytes = (size_t)plan->n * sizeof(T), in_bytes = cnt * sizeof(double);
-    const long long per_chunk = (long long)(kChunkInBytes / ((im_in ? 2 : 1) * row_bytes));
+    const size_t row_bytes = n * sizeof(T), out_bytes = cnt * sizeof(double), in_row_bytes = n * sizeof(double);
+    const long long per_chunk = (long long)(kChunkInBytes / ((has_im ? 2 : 1) * row_bytes));
     const int workers = host_workers(tables<T>(plan).log2n1 > 0);
-    const bool overlap = host_ranges_overlap(re_in, in_bytes, re_out, in_bytes) ||
-                         host_ranges_overlap(re_in, in_bytes, im_out, in_bytes) ||
-                         host_ranges_overlap(im_in, in_bytes, re_out, in_bytes) ||
-                         host_ranges_overlap(im_in, in_bytes, im_out, in_bytes);
+    bool overlap = false;
+    if (re_rows || im_rows) {
+      for (long long r = 0; r < batch && !overlap; ++r)
+        overlap = host_ranges_overlap(re_row(r), in_row_bytes, re_out, out_bytes) ||
+                  host_ranges_overlap(re_row(r), in_row_bytes, im_out, out_bytes) ||
+                  (has_im && (host_ranges_overlap(im_row(r), in_row_bytes, re_out, out_bytes) ||
+                              host_ranges_overlap(im_row(r), in_row_bytes, im_out, out_bytes)));
+    } else {
+      overlap = host_ranges_overlap(re_in, out_bytes, re_out, out_bytes) || host_ranges_overlap(re_in, out_bytes, im_out, out_bytes) ||
+                host_ranges_overlap(im_in, out_bytes, re_out, out_bytes) || host_ranges_overlap(im_in, out_bytes, im_out, out_bytes);
+    }
     if (workers >= 2 && per_chunk >= 1 && batch >= 2 * per_chunk && 4 * cnt * sizeof(T) >= kChunkedMinBytes && !overlap) {
-      const size_t slot = 4 * (size_t)per_chunk * (size_t)plan->n;  // elements: re | im | out re | out im
+      const size_t slot = 4 * (size_t)per_chunk * n;  // elements: re | im | out re | out im
       const int k = (long long)workers < (batch + per_chunk - 1) / per_chunk ? workers : (int)((batch + per_chunk - 1) / per_chunk);
       if (int rc = ensure_stage(plan, (size_t)k * slot * sizeof(T))) return rc;
-      const size_t n = (size_t)plan->n;
       return run_chunked(plan, batch, per_chunk, k, [&](const ChunkJob &job) -> int {
         const size_t c = (size_t)job.count * n, off = (size_t)job.first * n;
         T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
-        rows_to_stage<T>(h, re_in + off, c);
-        if (im_in) rows_to_stage<T>(h + c, im_in + off, c);
-        PDSP_HIP_TRY(hipMemcpyAsync(d, h, (im_in ? 2 : 1) * c * sizeof(T), hipMemcpyHostToDevice, job.stream));
+        stage_in(h, h + c, job.first, job.count);
+        PDSP_HIP_TRY(hipMemcpyAsync(d, h, (has_im ? 2 : 1) * c * sizeof(T), hipMemcpyHostToDevice, job.stream));
         int rc;
         if (inverse) rc = run_complex<T>(plan, job.count, d + c, d, d + 3 * c, d + 2 * c, T(1) / (T)plan->n, job.stream);
-        else rc = run_complex<T>(plan, job.count, d, im_in ? d + c : nullptr, d + 2 * c, d + 3 * c, T(1), job.stream);
+        else rc = run_complex<T>(plan, job.count, d, has_im ? d + c : nullptr, d + 2 * c, d + 3 * c, T(1), job.stream);
         if (rc) return rc;
         PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * c, d + 2 * c, 2 * c * sizeof(T), hipMemcpyDeviceToHost, job.stream));
         PDSP_HIP_TRY(hipStreamSynchronize(job.stream));
@@ -1731,26 +1751,24 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
   if (int rc = ensure_stage(plan, 4 * cnt * sizeof(T))) return rc;
   T *h_re = (T *)plan->h_stage, *h_im = h_re + cnt, *h_ore = h_im + cnt, *h_oim = h_ore + cnt;
   T *d_re = (T *)plan->d_stage, *d_im = d_re + cnt, *d_ore = d_im + cnt, *d_oim = d_ore + cnt;
-  for (size_t i = 0; i < cnt; ++i) h_re[i] = (T)re_in[i];
-  if (im_in)
-    for (size_t i = 0; i < cnt; ++i) h_im[i] = (T)im_in[i];
+  stage_in(h_re, h_im, 0, batch);
   hipStream_t s = plan->stream;
   T *const z = zero_copy(4 * cnt * sizeof(T)) ? stage_device_view<T>(plan) : nullptr;
   if (z) {  // the kernels work on the pinned buffer itself
     d_re = z, d_im = z + cnt, d_ore = z + 2 * cnt, d_oim = z + 3 * cnt;
   } else {
-    PDSP_HIP_TRY(hipMemcpyAsync(d_re, h_re, (im_in ? 2 : 1) * cnt * sizeof(T), hipMemcpyHostToDevice, s));
+    PDSP_HIP_TRY(hipMemcpyAsync(d_re, h_re, (has_im ? 2 : 1) * cnt * sizeof(T), hipMemcpyHostToDevice, s));
   }
   int rc;
   // inverse: conj(FFT(conj(z))) == swap(FFT(swap(z))) -- the conjugated-twiddle sweep of fft.ts:122
   // is the forward kernel with the planes exchanged on the way in and out; 1/N rides on the store
   if (inverse) rc = run_complex<T>(plan, batch, d_im, d_re, d_oim, d_ore, T(1) / (T)plan->n, s);
-  else rc = run_complex<T>(plan, batch, d_re, im_in ? d_im : nullptr, d_ore, d_oim, T(1), s);
+  else rc = run_complex<T>(plan, batch, d_re, has_im ? d_im : nullptr, d_ore, d_oim, T(1), s);
   if (rc) return rc;
   if (!z) PDSP_HIP_TRY(hipMemcpyAsync(h_ore, d_ore, 2 * cnt * sizeof(T), hipMemcpyDeviceToHost, s));
   PDSP_HIP_TRY(hipStreamSynchronize(s));
-  for (size_t i = 0; i < cnt; ++i) re_out[i] = (double)h_ore[i];
-  for (size_t i = 0; i < cnt; ++i) im_out[i] = (double)h_oim[i];
+  stage_to_rows<T>(re_out, h_ore, cnt);
+  stage_to_rows<T>(im_out, h_oim, cnt);
   return PDSP_OK;
 }
 
@@ -2245,8 +2263,27 @@ int pdsp_fft_transform_host_f64(pdsp_plan *plan, long long batch, long long in_l
   DeviceGuard g(plan->device);
   PDSP_HIP_TRY(g.err);
   const int rc = (host_precision() == 64 && plan->t64.tw)
-                     ? transform_host<double>(plan, batch, re_in, im_in, re_out, im_out, inverse)
-                     : transform_host<float>(plan, batch, re_in, im_in, re_out, im_out, inverse);
+                     ? transform_host<double>(plan, batch, re_in, im_in, nullptr, nullptr, re_out, im_out, inverse)
+                     : transform_host<float>(plan, batch, re_in, im_in, nullptr, nullptr, re_out, im_out, inverse);
+  trim_stage(plan);
+  return rc;
+}
+
+int pdsp_fft_transform_rows_host_f64(pdsp_plan *plan, long long batch, long long in_len, const double *const *re_rows,
+                                     const double *const *im_rows, double *re_out, double *im_out, int inverse) {
+  if (int rc = check_plan_batch(plan, batch)) return rc;
+  if (in_len != plan->n) return fail(PDSP_ERR_INPUT_LENGTH, "FFT input length %lld != size %lld", in_len, plan->n);
+  if (batch == 0) return PDSP_OK;
+  if (!re_rows || !re_out || !im_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  if (inverse && !im_rows) return fail(PDSP_ERR_BAD_ARG, "inverse needs an imaginary plane");
+  for (long long r = 0; r < batch; ++r)
+    if (!re_rows[r] || (im_rows && !im_rows[r])) return fail(PDSP_ERR_BAD_ARG, "null buffer");
+  std::lock_guard<std::mutex> lk(plan->mu);
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  const int rc = (host_precision() == 64 && plan->t64.tw)
+                     ? transform_host<double>(plan, batch, nullptr, nullptr, re_rows, im_rows, re_out, im_out, inverse)
+                     : transform_host<float>(plan, batch, nullptr, nullptr, re_rows, im_rows, re_out, im_out, inverse);
   trim_stage(plan);
   return rc;
 }

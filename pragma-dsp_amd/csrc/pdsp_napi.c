@@ -166,6 +166,88 @@ static napi_value TransformBatch(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* transformRows(plan, inputs, complex, outRe, outIm, inverse): inputs is a JS array of Float64Arrays (complex =
+ * false: real rows) or of { real, imag } pairs of Float64Arrays, every plane of the plan's size -- read where they
+ * lie (pdsp_fft_transform_rows_host_f64); outRe / outIm hold inputs.length * size values. */
+static napi_value TransformRows(napi_env env, napi_callback_info info) {
+  napi_value argv[6];
+  if (!get_args(env, info, 6, argv)) return NULL;
+  void *plan = NULL;
+  NAPI_OK_OR_THROW(env, napi_get_value_external(env, argv[0], &plan));
+  bool is_array = false, complex = false, inverse = false;
+  uint32_t batch = 0;
+  if (napi_is_array(env, argv[1], &is_array) != napi_ok || !is_array ||
+      napi_get_array_length(env, argv[1], &batch) != napi_ok) {
+    napi_throw_type_error(env, NULL, "pdsp_napi: transformRows expects an array of rows");
+    return NULL;
+  }
+  NAPI_OK_OR_THROW(env, napi_get_value_bool(env, argv[2], &complex));
+  double *ore, *oim;
+  size_t nore, noim;
+  if (!f64_array(env, argv[3], &ore, &nore) || !f64_array(env, argv[4], &oim, &noim)) return NULL;
+  NAPI_OK_OR_THROW(env, napi_get_value_bool(env, argv[5], &inverse));
+  const long long n = pdsp_plan_size((pdsp_plan *)plan);
+  if (n <= 0 || (size_t)batch > ((size_t)-1) / 16 / (size_t)n || nore != (size_t)batch * (size_t)n ||
+      noim != (size_t)batch * (size_t)n) {
+    napi_throw_error(env, NULL, "pdsp_napi: transformRows output planes must hold rows * size values");
+    return NULL;
+  }
+  if (inverse && !complex && batch > 0) {
+    napi_throw_error(env, NULL, "pdsp_napi: transformRows inverse needs complex rows");
+    return NULL;
+  }
+  const double **re = (const double **)malloc(sizeof(double *) * (size_t)(batch ? batch : 1));
+  const double **im = complex ? (const double **)malloc(sizeof(double *) * (size_t)(batch ? batch : 1)) : NULL;
+  if (!re || (complex && !im)) {
+    free(re);
+    free(im);
+    napi_throw_error(env, NULL, "pdsp_napi: out of memory");
+    return NULL;
+  }
+  for (uint32_t b = 0; b < batch; ++b) {
+    napi_handle_scope scope;
+    if (napi_open_handle_scope(env, &scope) != napi_ok) {
+      napi_throw_error(env, NULL, "pdsp_napi: N-API call failed: napi_open_handle_scope");
+      free(re);
+      free(im);
+      return NULL;
+    }
+    napi_value el, v;
+    double *p = NULL, *q = NULL;
+    size_t np = 0, nq = 0;
+    int ok = napi_get_element(env, argv[1], b, &el) == napi_ok;
+    if (ok && !complex) {
+      ok = f64_array(env, el, &p, &np);
+    } else if (ok) {
+      napi_valuetype t;
+      ok = napi_typeof(env, el, &t) == napi_ok && t == napi_object;
+      if (!ok) napi_throw_type_error(env, NULL, "pdsp_napi: transformRows expects { real, imag } rows");
+      ok = ok && napi_get_named_property(env, el, "real", &v) == napi_ok && f64_array(env, v, &p, &np) &&
+           napi_get_named_property(env, el, "imag", &v) == napi_ok && f64_array(env, v, &q, &nq);
+    }
+    bool pending = false;
+    if (!ok && napi_is_exception_pending(env, &pending) == napi_ok && !pending)
+      napi_throw_error(env, NULL, "pdsp_napi: N-API call failed while reading a row");
+    if (ok && ((long long)np != n || (complex && (long long)nq != n) || !p || (complex && !q))) {
+      napi_throw_error(env, NULL, "pdsp_napi: transformRows rows must be Float64Arrays of the plan's size");
+      ok = 0;
+    }
+    napi_close_handle_scope(env, scope);
+    if (!ok) {
+      free(re);
+      free(im);
+      return NULL;
+    }
+    re[b] = p;
+    if (complex) im[b] = q;
+  }
+  const int rc = pdsp_fft_transform_rows_host_f64((pdsp_plan *)plan, (long long)batch, n, re, im, ore, oim, inverse ? 1 : 0);
+  free(re);
+  free(im);
+  if (rc != PDSP_OK) return throw_pdsp(env);
+  return NULL;
+}
+
 /* windowMake(type, size, out)   [createWindow, fourier.ts:14-52] */
 static napi_value WindowMake(napi_env env, napi_callback_info info) {
   napi_value argv[3];
@@ -435,7 +517,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     napi_callback fn;
   } fns[] = {
       {"planCreate", PlanCreate}, {"transform", Transform},   {"windowMake", WindowMake},
-      {"transformBatch", TransformBatch},
+      {"transformBatch", TransformBatch}, {"transformRows", TransformRows},
       {"applyWindow", ApplyWindow}, {"magnitude", Magnitude}, {"phase", Phase},
       {"spectrum", Spectrum},     {"binFrequencies", BinFrequencies}, {"fftShift", FftShift},
       {"spectrumBatch", SpectrumBatch}, {"spectrumRows", SpectrumRows},

@@ -79,21 +79,27 @@ class Radix2Fft {
   _transformBatch(inputs, complex, inverse) {
     const batch = inputs.length >>> 0;
     const n = this.size;
-    const re = new Float64Array(batch * n);
-    const im = complex ? new Float64Array(batch * n) : null;
+    let typed = Array.isArray(inputs);  // every plane a Float64Array: the rows are read where they lie
     for (let b = 0; b < batch; b += 1) {
       const r = complex ? inputs[b].real : inputs[b];
       const i = complex ? inputs[b].imag : null;
       if (r.length !== n) throw new Error('FFT input length ' + r.length + ' != size ' + n);
       if (i && i.length !== n) throw new Error('FFT input length ' + i.length + ' != size ' + n);
-      re.set(toF64(r), b * n);
-      if (im) {
-        if (i) im.set(toF64(i), b * n);
-      }
+      typed = typed && r instanceof Float64Array && (!complex || i instanceof Float64Array);
     }
     const ore = new Float64Array(batch * n);
     const oim = new Float64Array(batch * n);
-    if (batch > 0) native.transformBatch(this._plan, batch, re, im, ore, oim, inverse);
+    if (batch > 0 && typed) {
+      native.transformRows(this._plan, inputs, complex, ore, oim, inverse);
+    } else if (batch > 0) {  // plain arrays, other typed arrays, holes (`?? 0`), a missing imag plane: flattened to f64
+      const re = new Float64Array(batch * n);
+      const im = complex ? new Float64Array(batch * n) : null;
+      for (let b = 0; b < batch; b += 1) {
+        re.set(toF64(complex ? inputs[b].real : inputs[b]), b * n);
+        if (im && inputs[b].imag) im.set(toF64(inputs[b].imag), b * n);
+      }
+      native.transformBatch(this._plan, batch, re, im, ore, oim, inverse);
+    }
     const out = new Array(batch);
     for (let b = 0; b < batch; b += 1) {
       out[b] = { real: ore.subarray(b * n, (b + 1) * n), imag: oim.subarray(b * n, (b + 1) * n) };

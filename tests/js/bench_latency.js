@@ -92,5 +92,36 @@ for (const n of [1024, 4096]) {
   const us = (now() - t0) / (reps * 256);
   out.cases.push({ n: n, op: 'spectrumBatch(256 frames, hann) per frame', gpu_dropin: { median_us: us, min_us: us, p95_us: us }, guard: acc });
 }
+// FFT.forwardBatch: the reference's batch idiom (bench/reallife/signals.ts:264-270, `for (...) fft.forward(input)`)
+// as one call, 256 rows, beside the same rows through 256 forward() calls and through the Node CPU path
+for (const n of [1024, 4096]) {
+  if (only) continue;
+  const rows = [];
+  for (let b = 0; b < 256; b++) {
+    const f = new Float64Array(n);
+    for (let i = 0; i < n; i++) f[i] = rnd();
+    rows.push(f);
+  }
+  const fft = new p.fourier.FFT(n);
+  for (let w = 0; w < 5; w++) fft.forwardBatch(rows);
+  const reps = 20;
+  let acc = 0;
+  let t0 = now();
+  for (let r = 0; r < reps; r++) acc += fft.forwardBatch(rows)[255].real[1];
+  const usBatch = (now() - t0) / (reps * 256);
+  const outc = fft.createComplexArray();
+  t0 = now();
+  for (let r = 0; r < 4; r++) for (let b = 0; b < 256; b++) acc += fft.forward(rows[b], outc).real[1];
+  const usLoop = (now() - t0) / (4 * 256);
+  const row = { n: n, op: 'FFT.forwardBatch(256 rows) per row', gpu_dropin: { median_us: usBatch, min_us: usBatch, p95_us: usBatch },
+                gpu_dropin_loop_of_forward: { median_us: usLoop }, guard: acc };
+  if (cpu) {
+    const plan = cpu.makePlan(n), oRe = new Float64Array(n), oIm = new Float64Array(n);
+    t0 = now();
+    for (let r = 0; r < 4; r++) for (let b = 0; b < 256; b++) { cpu.transform(plan, rows[b], null, oRe, oIm, false); acc += oRe[1]; }
+    row.node_cpu = { median_us: (now() - t0) / (4 * 256) };
+  }
+  out.cases.push(row);
+}
 out.checksum_guard = Number.isFinite(seed) ? 1 : 0;
 process.stdout.write(JSON.stringify(out) + '\n');

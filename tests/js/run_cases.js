@@ -104,6 +104,11 @@ const results = cases.map((c) => {
         const pick = [0, 1, Math.floor(c.count / 2), c.count - 1];
         let same = fwd.length === c.count;
         for (const i of pick) { const one = fft.forward(rows[i]); same = same && eq(fwd[i].real, one.real) && eq(fwd[i].imag, one.imag); }
+        // Float64Array rows are read where they lie (native.transformRows); a batch with plain arrays in it is
+        // flattened first (native.transformBatch): same values
+        const nm = Math.min(c.count, 40);
+        const mixed = fft.forwardBatch(rows.slice(0, nm).map((r, i) => (i % 2 ? Array.from(r) : r)));
+        for (const i of [0, 1, nm - 1]) same = same && eq(mixed[i].real, fwd[i].real) && eq(mixed[i].imag, fwd[i].imag);
         const cplx = rows.map((r, i) => ({ real: r, imag: rows[(i + 1) % c.count] }));
         const fc = fft.forwardComplexBatch(cplx);
         for (const i of pick) { const one = fft.forwardComplex(cplx[i]); same = same && eq(fc[i].real, one.real) && eq(fc[i].imag, one.imag); }

@@ -172,3 +172,32 @@ def test_rows_variant_equals_contiguous_frames(capi, precision, n, length, batch
     rc = capi.lib.pdsp_spectrum_rows_host_f64(rows, batch, length, 48000.0, n, 1, 0, capi.dptr(freq), capi.dptr(amp),
                                               capi.dptr(ph), peaks, None)
     assert rc == capi.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("n,batch", [(1024, 2100), (8, 3)])
+def test_transform_rows_variant_equals_contiguous_planes(capi, precision, n, batch):
+    """pdsp_fft_transform_rows_host_f64 (one pointer per input row) against pdsp_fft_transform_host_f64 on the same rows
+    as contiguous planes: identical, chunked or not, forward (real and complex) and inverse."""
+    capi.lib.pdsp_set_host_precision(precision)
+    rng = np.random.default_rng(11 + n)
+    re_rows = [rng.standard_normal(n) for _ in range(batch)]
+    im_rows = [rng.standard_normal(n) for _ in range(batch)]
+    re, im = np.stack(re_rows), np.stack(im_rows)
+    dp = C.POINTER(C.c_double)
+    rp = (dp * batch)(*[capi.dptr(r) for r in re_rows])
+    ip = (dp * batch)(*[capi.dptr(r) for r in im_rows])
+    plan = C.c_void_p()
+    capi.check(capi.lib.pdsp_plan_create(n, -1, C.byref(plan)))
+    try:
+        for threads in (1, 4):
+            for use_im, inverse in ((True, 0), (False, 0), (True, 1)):
+                want = _transform(capi, plan, re, im if use_im else None, inverse, threads)
+                ore, oim = np.full_like(re, np.nan), np.full_like(re, np.nan)
+                capi.check(capi.lib.pdsp_fft_transform_rows_host_f64(plan, batch, n, rp, ip if use_im else None, capi.dptr(ore),
+                                                                     capi.dptr(oim), inverse))
+                assert np.array_equal(ore, want[0]) and np.array_equal(oim, want[1])
+        assert capi.lib.pdsp_fft_transform_rows_host_f64(plan, batch, n + 1, rp, ip, capi.dptr(ore), capi.dptr(oim), 0) == capi.ERR_INPUT_LENGTH
+        assert capi.lib.pdsp_fft_transform_rows_host_f64(plan, batch, n, rp, None, capi.dptr(ore), capi.dptr(oim), 1) == capi.ERR_BAD_ARG
+    finally:
+        capi.lib.pdsp_plan_destroy(plan)

@@ -252,7 +252,7 @@ def test_napi_addon_argument_handling_under_address_sanitizer(tmp_path):
                  "spectrum bad size", "spectrumRows not an array", "spectrumRows range past the end",
                  "spectrumRows negative start", "spectrumRows ragged frame", "spectrumRows plain-array frame",
                  "spectrumRows hole", "spectrumRows short out", "spectrumRows bad size", "spectrumRows bad rate",
-                 "transformBatch wrong plan"):
+                 "transformBatch wrong plan", "transformRows wrong plan", "transformRows not an array"):
         assert log[name][0] == "throws", (name, log[name])
     assert log["spectrumRows bad size"] == ("throws", "FFT size must be power of two, got 12")
     assert log["spectrumRows bad rate"] == ("throws", "Sample rate must be positive, got 0")
