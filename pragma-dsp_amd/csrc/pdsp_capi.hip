@@ -2,6 +2,9 @@
 // reference's error texts, plan objects, kernel dispatch by size, and the
 // synchronous host-f64 entry points the JS drop-in binds.
 //
+// Host side only: no kernel is instantiated in this translation unit (the dispatchers it calls -- run_complex,
+// spectrum_impl, ... -- are declared in pdsp_internal.h and live in the pdsp_kernels_*.hip units).
+//
 // Product path only: nothing here touches oracle/, and there is no CPU fallback --
 // without a HIP device every compute entry point fails with PDSP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
@@ -19,11 +22,9 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/pdsp_hip.h"
-#include "../../include/pdsp_hip_dev.h"
-#include "pdsp_fft_kernel.h"
+#include "pdsp_internal.h"
 
-namespace {
+namespace pdsp_host {
 
 thread_local std::string g_err;
 // development switches (tools / tests): 0 routes N = 16384 spectra to spectrum_packed_kernel<13>,
@@ -45,19 +46,6 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
-#define PDSP_HIP_TRY(expr)                                                              \
-  do {                                                                                  \
-    hipError_t e_ = (expr);                                                             \
-    if (e_ != hipSuccess)                                                               \
-      return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #expr); \
-  } while (0)
-
-// Stream-ordered scratch that is handed back on every exit path.
-// Stream-ordered scratch planes of the multi-pass paths, from a pool of the engine's own per device whose release
-// threshold is unlimited: the device's default pool hands its memory back at every synchronisation, so that a
-// caller who synchronises between transforms (every host-f64 call does) paid a fresh 1-2 GiB allocation --
-// a trip through the kernel driver, observed to stall for 0.5-1 s on a busy host -- on each call.  Here the planes
-// of the largest transform seen stay with the engine until pdsp_plan_cache_clear() trims the pools.
 constexpr int kMaxPoolDevices = 64;
 hipMemPool_t g_scratch_pool[kMaxPoolDevices] = {};
 std::mutex g_scratch_pool_mu;
@@ -81,29 +69,7 @@ hipMemPool_t scratch_pool() {
   }
   return g_scratch_pool[dev];
 }
-void trim_scratch_pools();
-
-// Bytes of scratch planes this process has drawn from the pools since they were last trimmed: pdsp_plan_destroy()
-// hands the pools' unused memory back to the device when a plan that needs scratch (N beyond the single-pass
-// limit) goes away and anything was drawn -- otherwise GiBs of HBM stay pinned where the caller's allocator
-// (PyTorch's, say) cannot see them, long after the last large transform.
 std::atomic<unsigned long long> g_scratch_drawn{0};
-
-struct StreamScratch {
-  void *p = nullptr;
-  hipStream_t s;
-  explicit StreamScratch(hipStream_t stream) : s(stream) {}
-  StreamScratch(const StreamScratch &) = delete;
-  StreamScratch &operator=(const StreamScratch &) = delete;
-  hipError_t alloc(size_t bytes) {
-    g_scratch_drawn += bytes;
-    if (hipMemPool_t pool = scratch_pool()) return hipMallocFromPoolAsync(&p, bytes, pool, s);
-    return hipMallocAsync(&p, bytes, s);  // no pool of our own on this device: the default one
-  }
-  ~StreamScratch() {
-    if (p) (void)hipFreeAsync(p, s);
-  }
-};
 
 void trim_scratch_pools() {
   std::lock_guard<std::mutex> lk(g_scratch_pool_mu);
@@ -112,131 +78,9 @@ void trim_scratch_pools() {
   g_scratch_drawn = 0;
 }
 
-struct DeviceGuard {
-  int prev = -1;
-  bool switched = false;
-  hipError_t err = hipSuccess;
-  explicit DeviceGuard(int dev) {
-    err = hipGetDevice(&prev);
-    if (err == hipSuccess && dev >= 0 && dev != prev) {
-      err = hipSetDevice(dev);
-      switched = (err == hipSuccess);
-    }
-  }
-  ~DeviceGuard() {
-    if (switched) (void)hipSetDevice(prev);
-  }
-};
+}  // namespace pdsp_host
 
-int ilog2ll(long long n) {
-  int l = 0;
-  while ((1LL << l) < n) ++l;
-  return l;
-}
-
-}  // namespace
-
-// Device tables of one precision.
-template <typename T>
-struct Tables {
-  using T2 = typename pdsp::vec2<T>::type;
-  T2 *tw = nullptr;       // inter-pass twiddles of the N-point transform (pdsp_radix.h layout)
-  // packed-real spectrum path (N >= 64): radix table of the N/2-point transform and the
-  // split twiddles W_N^k, 0 <= k <= N/4
-  T2 *tw_half = nullptr;
-  T2 *twr = nullptr;
-  T2 *tw12 = nullptr;  // N = 16384 only: radix table of the 4096-point sub-transforms (split kernels)
-  T2 *tws4 = nullptr;  // rows of 16384 points (log2n2 == 14): W_16384^k, k < 768 (fft_split4_kernel)
-  T2 *tws2 = nullptr;  // rows of 8192 points (log2n2 == 13): W_8192^k, k < 256 (fft_split2_kernel; uses tw12 too)
-  T *win[4] = {nullptr, nullptr, nullptr, nullptr};  // createWindow(type, N), built on first use
-  // N = 16384, f32: per-thread bases and per-q constants of the fused cosine-sum windows
-  // (spectrum_dif16k_kernel, WinFused): cos / sin of f*(2 tid + e) and of f*512 q (+ 8192), f = 2 pi / (N - 1)
-  float *wf_base = nullptr;
-  float *wf_step = nullptr;
-  // four-step path (N beyond the single-pass limit): `tw` then belongs to the N2-point rows,
-  // N1 = N / N2, and W_N^m = twa[m >> 9] * twb[m & 511]
-  int log2n2 = 0;  // log2 of the transform `tw` serves (== log2 N when single-pass)
-  int log2n1 = 0;
-  T2 *twa = nullptr;
-  T2 *twb = nullptr;
-  T2 *tw1 = nullptr;  // general four-step path (log2n1 > kMaxLog2N1): radix table of the N1-point rows
-  // tile passes (f32): N = product of tp_np balanced factors 2^tp_l[i] (two for 2^15..2^18, three for
-  // 2^19..2^27), radix table of each factor's transform
-  int tp_np = 0;
-  int tp_l[3] = {0, 0, 0};
-  T2 *tp_tw[3] = {nullptr, nullptr, nullptr};
-  T2 *tw8 = nullptr;  // radix table of the 256-point transform (tile_rows512_kernel's halves of a 512-point factor)
-  // the same for the N/2-point transform of the packed-real spectrum path (2^15 <= N <= 2^27): it runs on
-  // this plan's twa / twb with doubled exponents (TileGeom::tshift)
-  int hp_np = 0;
-  int hp_l[3] = {0, 0, 0};
-  T2 *hp_tw[3] = {nullptr, nullptr, nullptr};
-  float *hp_win = nullptr;  // angle-addition tables of the fused cosine-sum windows (TileGeom::wa ...): wa | wb | wstep | we
-  size_t hp_win_a = 0;      // entries (cos, sin pairs) of wa
-  void release() {
-    if (tw12) (void)hipFree(tw12);
-    tw12 = nullptr;
-    if (wf_base) (void)hipFree(wf_base);
-    if (wf_step) (void)hipFree(wf_step);
-    wf_base = wf_step = nullptr;
-    if (tws4) (void)hipFree(tws4);
-    tws4 = nullptr;
-    if (tws2) (void)hipFree(tws2);
-    tws2 = nullptr;
-
-    if (tw8) (void)hipFree(tw8);
-    tw8 = nullptr;
-    for (T2 *&q : tp_tw) {
-      if (q) (void)hipFree(q);
-      q = nullptr;
-    }
-    tp_np = 0;
-    for (T2 *&q : hp_tw) {
-      if (q) (void)hipFree(q);
-      q = nullptr;
-    }
-    hp_np = 0;
-    if (hp_win) (void)hipFree(hp_win);
-    hp_win = nullptr;
-    if (twa) (void)hipFree(twa);
-    if (twb) (void)hipFree(twb);
-    if (tw1) (void)hipFree(tw1);
-    twa = twb = tw1 = nullptr;
-    if (tw) (void)hipFree(tw);
-    if (tw_half) (void)hipFree(tw_half);
-    if (twr) (void)hipFree(twr);
-    for (T *&w : win) {
-      if (w) (void)hipFree(w);
-      w = nullptr;
-    }
-    tw = tw_half = twr = nullptr;
-  }
-};
-
-struct pdsp_plan {
-  long long n = 0;
-  int log2n = 0;
-  int device = -1;
-  Tables<float> t32;
-  Tables<double> t64;  // present when the f64 single-pass kernels take this size
-  // host-f64 entry points: one stream + growing staging buffers per plan
-  std::mutex mu;
-  hipStream_t stream = nullptr;
-  void *h_stage = nullptr;  // pinned
-  size_t h_bytes = 0;
-  void *d_stage = nullptr;
-  size_t d_bytes = 0;
-  // batched host calls large enough to be cut into chunks (run_chunked): one stream per staging slot
-  std::vector<hipStream_t> slot_streams;
-};
-
-template <typename T> Tables<T> &tables(pdsp_plan *p);
-template <> Tables<float> &tables<float>(pdsp_plan *p) { return p->t32; }
-template <> Tables<double> &tables<double>(pdsp_plan *p) { return p->t64; }
-template <typename T> const Tables<T> &tables(const pdsp_plan *p) { return tables<T>(const_cast<pdsp_plan *>(p)); }
-
-// Largest log2 N of the single-pass kernels: (N + N/16) complex values must fit 160 KiB of LDS.
-template <typename T> constexpr int max_log2n() { return sizeof(T) == 4 ? pdsp::kMaxLog2N_f32 : pdsp::kMaxLog2N_f64; }
+using namespace pdsp_host;
 
 namespace {
 
@@ -261,655 +105,6 @@ std::vector<T2> build_twiddles(int log2n, int log2e = 4) {
       }
   }
   return tw;
-}
-
-// Factors of a three-pass transform of 2^lg points (2^18 < 2^lg <= 2^27): balanced, ascending.  (Tried and
-// dropped: a 64-point first factor everywhere -- the widest tiles for the one pass that reads strided -- with
-// 512-point factors behind it: 2^22 as 64 * 256 * 256 and 2^24 as 64 * 512 * 512 measured -3 % / +1 % against
-// 128 * 128 * 256 and 256^3, the long-frame spectrum -2 ... -5 %: profiles/r02_experiments/sweep_large_factors.log.)
-inline void three_factors(int lg, int *l) {
-  l[0] = lg / 3, l[1] = (lg - l[0]) / 2, l[2] = lg - l[0] - l[1];
-}
-
-template <typename T, int LOG2N, class LD, class ST>
-hipError_t launch_one(const LD &ld, const ST &st, const typename pdsp::vec2<T>::type *tw, long long batch,
-                      hipStream_t s) {
-  if constexpr (LOG2N > max_log2n<T>()) {
-    return hipErrorInvalidValue;  // would not fit LDS; never instantiated
-  } else {
-    using TR = pdsp::FftTraits<LOG2N>;
-    const long long blocks = (batch + TR::ROWS - 1) / TR::ROWS;
-    hipLaunchKernelGGL((pdsp::fft_stockham_kernel<T, LOG2N, LD, ST>), dim3((unsigned)blocks), dim3(TR::WG), 0, s, ld,
-                       st, tw, batch);
-    return hipGetLastError();
-  }
-}
-
-template <typename T, class LD, class ST>
-hipError_t launch_fft(int log2n, const LD &ld, const ST &st, const typename pdsp::vec2<T>::type *tw, long long batch,
-                      hipStream_t s) {
-  switch (log2n) {
-#define PDSP_CASE(L) \
-  case L:            \
-    return launch_one<T, L>(ld, st, tw, batch, s);
-    PDSP_CASE(0) PDSP_CASE(1) PDSP_CASE(2) PDSP_CASE(3) PDSP_CASE(4) PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7)
-    PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12) PDSP_CASE(13) PDSP_CASE(14)
-#undef PDSP_CASE
-    default:
-      return hipErrorInvalidValue;
-  }
-}
-
-// The same for N <= 32 only (spectrum() of frames below the packed-real path's sizes: LoadFrameWindowed /
-// StoreAmplitude are not instantiated for the sizes that never take them).
-template <typename T, class LD, class ST>
-hipError_t launch_fft_small(int log2n, const LD &ld, const ST &st, const typename pdsp::vec2<T>::type *tw, long long batch,
-                            hipStream_t s) {
-  switch (log2n) {
-#define PDSP_CASE(L) \
-  case L:            \
-    return launch_one<T, L>(ld, st, tw, batch, s);
-    PDSP_CASE(0) PDSP_CASE(1) PDSP_CASE(2) PDSP_CASE(3) PDSP_CASE(4) PDSP_CASE(5)
-#undef PDSP_CASE
-    default:
-      return hipErrorInvalidValue;
-  }
-}
-
-// Rows of planar complex points: N = 16384 (f32) goes to fft_split4_kernel when the input planes
-// allow 16-byte loads, everything else to the single-pass kernel of its size.
-template <typename T, class LD, class ST>
-hipError_t launch_rows(const Tables<T> &t, int log2n, const LD &ld, const ST &st, long long batch, hipStream_t s,
-                       bool aligned16) {
-  if constexpr (sizeof(T) == 4) {
-    if (log2n == 14 && g_split16k && aligned16 && t.tws4 && t.tw12) {
-      hipLaunchKernelGGL((pdsp::fft_split4_kernel<T, 12, LD, ST>), dim3((unsigned)batch), dim3(256), 0, s, ld, st,
-                         t.tw12, t.tws4, batch);
-      return hipGetLastError();
-    }
-  }
-  // N = 8192: measured on one box, f64 C2C 4.35 -> 5.80 TB/s, f64 real-in 4.0 -> 5.6, f32 real-in 5.4 -> 5.7,
-  // f32 C2C a wash (stays on the single-pass kernel)
-  // (f64 real rows run on fft_real_kernel; their LoadReal form of this kernel spilled 37 registers and is not built)
-  if constexpr (!(sizeof(T) == 8 && !LD::kHasIm)) {
-    if (log2n == 13 && (sizeof(T) == 8 || !LD::kHasIm || g_split8k_f32) && g_split16k && aligned16 && t.tws2 && t.tw12) {
-      hipLaunchKernelGGL((pdsp::fft_split2_kernel<T, LD, ST>), dim3((unsigned)batch), dim3(256), 0, s, ld, st, t.tw12,
-                         t.tws2, batch);
-      return hipGetLastError();
-    }
-  }
-  return launch_fft<T>(log2n, ld, st, t.tw, batch, s);
-}
-
-
-template <typename T, int LOG2M>
-hipError_t launch_packed_one(bool fast, const T *frames, const T *win, int wmode, pdsp::WinFused wf, long long frame_len,
-                             long long stride, const typename pdsp::vec2<T>::type *tw,
-                             const typename pdsp::vec2<T>::type *twr, T *amp, T *ph, int two_sided, T s_edge, T s_mid,
-                             pdsp::PeakRec *peaks, T freq_scale, long long batch, hipStream_t s) {
-  using TR = pdsp::FftTraits<LOG2M, pdsp::packed_log2e(LOG2M)>;
-  const long long ngroups = (batch + TR::ROWS - 1) / TR::ROWS;
-  const dim3 block(TR::WG);
-#define PDSP_LAUNCH(F, W, P)                                                                                  \
-  hipLaunchKernelGGL((pdsp::spectrum_packed_kernel<T, LOG2M, F, W, P>), dim3((unsigned)ngroups), block, 0, s, \
-                     frames, win, wf, frame_len, stride, tw, twr, amp, ph, two_sided, s_edge, s_mid, peaks, freq_scale, \
-                     batch)
-#define PDSP_LAUNCH_FW(F, W)                            \
-  do {                                                  \
-    if constexpr (sizeof(T) == 4) {                     \
-      if (peaks) PDSP_LAUNCH(F, W, true);               \
-      else PDSP_LAUNCH(F, W, false);                    \
-    } else {                                            \
-      PDSP_LAUNCH(F, W, false); /* fused peaks: f32 only */ \
-    }                                                   \
-  } while (0)
-  // fused cosine-sum windows (wmode 2 / 3): whole f32 frames of N = 1024 ... 8192 (the sizes whose plans
-  // carry the angle-addition tables); everything else reads the window as a table
-  if constexpr (sizeof(T) == 4 && LOG2M >= 9 && LOG2M <= 12) {
-    if (fast && wmode == 2) {
-      PDSP_LAUNCH_FW(true, 2);
-      return hipGetLastError();
-    }
-    if (fast && wmode == 3) {
-      PDSP_LAUNCH_FW(true, 3);
-      return hipGetLastError();
-    }
-  }
-  if (fast && win) PDSP_LAUNCH_FW(true, 1);
-  else if (fast) PDSP_LAUNCH_FW(true, 0);
-  else if (win) PDSP_LAUNCH_FW(false, 1);
-  else PDSP_LAUNCH_FW(false, 0);
-#undef PDSP_LAUNCH_FW
-#undef PDSP_LAUNCH
-  return hipGetLastError();
-}
-
-template <typename T, class... A>
-hipError_t launch_packed(int log2m, A... a) {
-  switch (log2m) {
-#define PDSP_CASE(L) \
-  case L:            \
-    return launch_packed_one<T, L>(a...);
-    PDSP_CASE(5) PDSP_CASE(6) PDSP_CASE(7) PDSP_CASE(8) PDSP_CASE(9) PDSP_CASE(10) PDSP_CASE(11) PDSP_CASE(12)
-    PDSP_CASE(13)
-#undef PDSP_CASE
-    default:
-      return hipErrorInvalidValue;
-  }
-}
-
-template <typename T>
-hipError_t launch_real(int log2m, const T *x, T *ore, T *oim, T scale, const typename pdsp::vec2<T>::type *tw,
-                       const typename pdsp::vec2<T>::type *twr, long long batch, hipStream_t s) {
-  switch (log2m) {
-#define PDSP_CASE(L)                                                                                              \
-  case L: {                                                                                                       \
-    using TR = pdsp::FftTraits<L, 4>;                                                                             \
-    hipLaunchKernelGGL((pdsp::fft_real_kernel<T, L>), dim3((unsigned)((batch + TR::ROWS - 1) / TR::ROWS)), dim3(TR::WG), \
-                       0, s, x, ore, oim, scale, tw, twr, batch);                                                 \
-    return hipGetLastError();                                                                                     \
-  }
-    PDSP_CASE(12) PDSP_CASE(13)
-#undef PDSP_CASE
-    default:
-      return hipErrorInvalidValue;
-  }
-}
-
-int check_plan_batch(const pdsp_plan *plan, long long batch) {
-  if (!plan) return fail(PDSP_ERR_BAD_ARG, "plan is null");
-  if (batch < 0) return fail(PDSP_ERR_BAD_ARG, "batch must be >= 0, got %lld", batch);
-  // grid.x limit; far beyond any HBM-resident batch
-  if (batch > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
-  return PDSP_OK;
-}
-
-// Four-step transform of `batch` rows of N = N1*N2 points into scratch planes (pass A + B);
-// the caller runs pass C.  REAL rows may carry a window and be shorter than N.
-template <typename T>
-int fourstep_ab(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, const T *win,
-                long long in_stride, long long frame_len, T *s_re, T *s_im, hipStream_t s) {
-  const Tables<T> &t = tables<T>(plan);
-  const int n2 = 1 << t.log2n2;
-  const long long blocks = batch * (n2 / 256);
-  if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
-  const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
-  const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
-#define PDSP_COLS(L, R, W)                                                                                        \
-  hipLaunchKernelGGL((pdsp::fourstep_cols_kernel<T, L, R, W>), dim3((unsigned)blocks), dim3(256), 0, s, re_in, im_in, \
-                     win, s_re, s_im, twa, twb, n2, in_stride, frame_len, batch)
-#define PDSP_COLS_L(L)                     \
-  do {                                     \
-    if (im_in) PDSP_COLS(L, false, false); \
-    else if (win) PDSP_COLS(L, true, true); \
-    else PDSP_COLS(L, true, false);        \
-  } while (0)
-  switch (t.log2n1) {
-    case 1: PDSP_COLS_L(1); break;
-    case 2: PDSP_COLS_L(2); break;
-    case 3: PDSP_COLS_L(3); break;
-    case 4: PDSP_COLS_L(4); break;
-    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported four-step split");
-  }
-#undef PDSP_COLS_L
-#undef PDSP_COLS
-  PDSP_HIP_TRY(hipGetLastError());
-  // pass B: the N1 * batch rows of N2 points, in place (each workgroup loads its row before it stores)
-  pdsp::LoadComplex<T> ld{s_re, s_im, n2};
-  pdsp::StoreComplex<T> st{s_re, s_im, n2, T(1)};
-  PDSP_HIP_TRY(launch_rows<T>(t, t.log2n2, ld, st, batch << t.log2n1, s, true));  // scratch planes are aligned
-  return PDSP_OK;
-}
-
-template <typename T, int MODE>
-int fourstep_c(const pdsp_plan *plan, long long batch, const T *s_re, const T *s_im, T *o1, T *o2, T scale, int bins,
-               int nyq, T s_edge, T s_mid, hipStream_t s) {
-  const Tables<T> &t = tables<T>(plan);
-  const int n2 = 1 << t.log2n2;
-  const long long blocks = batch * (n2 / 256);
-#define PDSP_OUT(L)                                                                                              \
-  hipLaunchKernelGGL((pdsp::fourstep_out_kernel<T, L, MODE>), dim3((unsigned)blocks), dim3(256), 0, s, s_re, s_im, o1, \
-                     o2, n2, scale, bins, nyq, s_edge, s_mid, batch)
-  switch (t.log2n1) {
-    case 1: PDSP_OUT(1); break;
-    case 2: PDSP_OUT(2); break;
-    case 3: PDSP_OUT(3); break;
-    case 4: PDSP_OUT(4); break;
-    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported four-step split");
-  }
-#undef PDSP_OUT
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
-
-// fft_staged_kernel on planar complex rows of 32 <= N <= 256 points (16-byte aligned planes).
-template <typename T>
-hipError_t launch_staged_complex(int log2n, const pdsp::LoadComplex<T> &ld, const pdsp::StoreComplex<T> &st,
-                                 const typename pdsp::vec2<T>::type *tw, long long rows, hipStream_t s) {
-  const long long blocks = ((rows << log2n) + 4095) / 4096;
-#define PDSP_STAGED_C(L)                                                                                  \
-  hipLaunchKernelGGL((pdsp::fft_staged_kernel<T, L, pdsp::LoadComplex<T>, pdsp::StoreComplex<T>>),         \
-                     dim3((unsigned)blocks), dim3(256), 0, s, ld, st, tw, rows)
-  switch (log2n) {
-    case 5: PDSP_STAGED_C(5); break;
-    case 6: PDSP_STAGED_C(6); break;
-    case 7: PDSP_STAGED_C(7); break;
-    case 8: PDSP_STAGED_C(8); break;
-    default: return hipErrorInvalidValue;
-  }
-#undef PDSP_STAGED_C
-  return hipGetLastError();
-}
-
-// findPeak over stored amplitude rows: index array and/or SpectrumPeak records.
-template <typename T>
-hipError_t launch_peaks(const T *amp, const T *ph, int bins, T freq_scale, int32_t *peak_idx, pdsp_peak32 *peaks,
-                        long long batch, hipStream_t s) {
-  pdsp::PeakRec *recs = reinterpret_cast<pdsp::PeakRec *>(peaks);
-  if (bins <= 2048) {  // one wave per row
-    hipLaunchKernelGGL((pdsp::peak_wave_kernel<T>), dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, s, amp, ph, bins,
-                       freq_scale, peak_idx, recs, batch);
-    return hipGetLastError();
-  }
-  if (peak_idx) hipLaunchKernelGGL((pdsp::find_peak_kernel<T>), dim3((unsigned)batch), dim3(256), 0, s, amp, bins, peak_idx, batch);
-  if (recs)
-    hipLaunchKernelGGL((pdsp::peak_from_rows_kernel<T>), dim3((unsigned)batch), dim3(256), 0, s, amp, ph, bins, freq_scale,
-                       recs, batch);
-  return hipGetLastError();
-}
-
-// fft_tiny_staged_kernel for 2 <= N <= 16 (one thread per row, chunk staged through LDS).
-template <typename T, bool AMP, class LD>
-hipError_t launch_tiny(int log2n, const LD &ld, const T *win, T *o1, T *o2, T scale, int bins, int nyq, T s_edge,
-                       T s_mid, long long batch, hipStream_t s) {
-  const long long blocks = ((batch << log2n) + 4095) / 4096;
-#define PDSP_TINY(L)                                                                                             \
-  hipLaunchKernelGGL((pdsp::fft_tiny_staged_kernel<T, L, AMP, LD>), dim3((unsigned)blocks), dim3(256), 0, s, ld, win, \
-                     o1, o2, scale, bins, nyq, s_edge, s_mid, batch)
-  switch (log2n) {
-    case 1: PDSP_TINY(1); break;
-    case 2: PDSP_TINY(2); break;
-    case 3: PDSP_TINY(3); break;
-    case 4: PDSP_TINY(4); break;
-    case 5:
-      if constexpr (AMP) {  // N = 32 transforms have fft_staged_kernel; the spectrum of N = 32 frames comes here
-        PDSP_TINY(5);
-        break;
-      }
-      return hipErrorInvalidValue;
-    default: return hipErrorInvalidValue;
-  }
-#undef PDSP_TINY
-  return hipGetLastError();
-}
-
-// General four-step path (log2n1 > kMaxLog2N1), steps 1-4 of bigfft_transpose_kernel's header:
-// transposes `in` into (a_re, a_im) = [n2][n1], N1-point rows in place, twiddled transpose into
-// (b_re, b_im) = [k1][n2], N2-point rows in place.  Step 5 is bigfft_out.
-template <typename T>
-int bigfft_rows(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, const T *win,
-                long long in_stride, long long used, T *a_re, T *a_im, T *b_re, T *b_im, hipStream_t s) {
-  const Tables<T> &t = tables<T>(plan);
-  const int n1 = 1 << t.log2n1, n2 = 1 << t.log2n2;
-  const long long tiles = batch * (plan->n / 1024);
-  if (tiles >= (1LL << 31) || (batch << t.log2n2) >= (1LL << 31))
-    return fail(PDSP_ERR_BAD_ARG, "batch %lld is too large for FFT size %lld", batch, plan->n);
-  hipLaunchKernelGGL((pdsp::bigfft_transpose_kernel<T, false, false>), dim3((unsigned)tiles), dim3(256), 0, s, re_in,
-                     im_in, win, used, in_stride, t.twa, t.twb, a_re, a_im, n1, n2, T(1), 0, 0, T(0), T(0));
-  PDSP_HIP_TRY(hipGetLastError());
-  {
-    pdsp::LoadComplex<T> ld{a_re, a_im, n1};
-    pdsp::StoreComplex<T> st{a_re, a_im, n1, T(1)};
-    if (t.log2n1 == t.log2n2) PDSP_HIP_TRY(launch_rows<T>(t, t.log2n1, ld, st, batch << t.log2n2, s, true));
-    else if (t.log2n1 <= (sizeof(T) == 4 ? 8 : 7) && g_staged_small)  // short rows: the staged kernel's coalesced I/O
-      PDSP_HIP_TRY(launch_staged_complex<T>(t.log2n1, ld, st, t.tw1, batch << t.log2n2, s));
-    else PDSP_HIP_TRY(launch_fft<T>(t.log2n1, ld, st, t.tw1, batch << t.log2n2, s));
-  }
-  hipLaunchKernelGGL((pdsp::bigfft_transpose_kernel<T, true, false>), dim3((unsigned)tiles), dim3(256), 0, s, a_re, a_im,
-                     (const T *)nullptr, plan->n, plan->n, t.twa, t.twb, b_re, b_im, n2, n1, T(1), 0, 0, T(0), T(0));
-  PDSP_HIP_TRY(hipGetLastError());
-  pdsp::LoadComplex<T> ld{b_re, b_im, n2};
-  pdsp::StoreComplex<T> st{b_re, b_im, n2, T(1)};
-  PDSP_HIP_TRY(launch_rows<T>(t, t.log2n2, ld, st, batch << t.log2n1, s, true));
-  return PDSP_OK;
-}
-
-// Step 5: [k1][k2] -> natural order.  AMP = false: complex planes (o1, o2) times `scale`;
-// AMP = true: amplitude rows o1 (and phase rows o2 unless null) of `bins` values.
-template <typename T, bool AMP>
-int bigfft_out(const pdsp_plan *plan, long long batch, const T *b_re, const T *b_im, T *o1, T *o2, T scale, int bins,
-               int nyq, T s_edge, T s_mid, hipStream_t s) {
-  const Tables<T> &t = tables<T>(plan);
-  const long long tiles = batch * (plan->n / 1024);
-  hipLaunchKernelGGL((pdsp::bigfft_transpose_kernel<T, false, AMP>), dim3((unsigned)tiles), dim3(256), 0, s, b_re, b_im,
-                     (const T *)nullptr, plan->n, plan->n, t.twa, t.twb, o1, o2, 1 << t.log2n1, 1 << t.log2n2, scale,
-                     bins, nyq, s_edge, s_mid);
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
-
-// One launch of tile_pass_kernel for a factor of 2^l points (tile width by factor: 64 / 32 / 32 / 16).
-// real_in = tile_pass_kernel's IN: 0 complex planes, 1 real rows (in_im unused), 2 real rows times the window table
-// in in_im, 3 / 4 the same for packed real rows (two samples per point)
-template <typename T, bool COLS>
-int tile_pass(int l, int real_in, const T *in_re, const T *in_im, T *out_re, T *out_im,
-              const typename pdsp::vec2<T>::type *tw, const Tables<T> &t, pdsp::TileGeom g, T scale, long long batch,
-              hipStream_t s) {
-  const long long blocks = batch * g.nblk * g.tiles;
-  if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
-  const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
-  const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
-  if constexpr (COLS && sizeof(T) == 4) {
-    // a 512-point factor as a column pass: 32-column tiles through tile_cols512_kernel (128-byte strided segments)
-    // instead of 16-column ones; pdsp_set_twopass bit 1 keeps the plain tiles (A/B tests)
-    if (l == 9 && real_in <= 1 && t.tw8 && !(g_twopass & 2) && g.tiles % 2 == 0) {
-      g.tiles /= 2;
-      const long long wide = batch * g.nblk * g.tiles;
-      if (real_in == 1)
-        hipLaunchKernelGGL((pdsp::tile_cols512_kernel<T, 1>), dim3((unsigned)wide), dim3(256), 0, s, in_re, in_im, out_re,
-                           out_im, t.tw8, twa, twb, g, batch);
-      else
-        hipLaunchKernelGGL((pdsp::tile_cols512_kernel<T, 0>), dim3((unsigned)wide), dim3(256), 0, s, in_re, in_im, out_re,
-                           out_im, t.tw8, twa, twb, g, batch);
-      PDSP_HIP_TRY(hipGetLastError());
-      return PDSP_OK;
-    }
-  }
-  if constexpr (!COLS && sizeof(T) == 4) {
-    // a 512-point factor as the last pass: 32-row tiles through tile_rows512_kernel (128-byte output segments)
-    // instead of 16-row ones; pdsp_set_twopass bit 1 keeps the plain tiles (A/B tests)
-    if (l == 9 && t.tw8 && !(g_twopass & 2) && g.tiles % 2 == 0) {
-      g.tiles /= 2;
-      const long long wide = batch * g.tiles;
-      hipLaunchKernelGGL((pdsp::tile_rows512_kernel<T>), dim3((unsigned)wide), dim3(256), 0, s, in_re, in_im, out_re, out_im,
-                         t.tw8, twa, twb, g, scale, batch);
-      PDSP_HIP_TRY(hipGetLastError());
-      return PDSP_OK;
-    }
-  }
-#define PDSP_TILE_IN(L, TILE, IN)                                                                                  \
-  hipLaunchKernelGGL((pdsp::tile_pass_kernel<T, L, TILE, COLS, ((COLS && (IN < 5 || sizeof(T) == 4)) ? IN : 0)>),    \
-                     dim3((unsigned)blocks), dim3(256),                                                               \
-                     0, s, in_re, in_im, out_re, out_im, tw, twa, twb, g, scale, batch)
-#define PDSP_TILE(L, TILE)                                 \
-  do {                                                     \
-    switch (COLS ? real_in : 0) {                          \
-      case 1: PDSP_TILE_IN(L, TILE, 1); break;             \
-      case 2: PDSP_TILE_IN(L, TILE, 2); break;             \
-      case 3: PDSP_TILE_IN(L, TILE, 3); break;             \
-      case 4: PDSP_TILE_IN(L, TILE, 4); break;             \
-      case 5: PDSP_TILE_IN(L, TILE, 5); break;             \
-      case 6: PDSP_TILE_IN(L, TILE, 6); break;             \
-      default: PDSP_TILE_IN(L, TILE, 0); break;            \
-    }                                                      \
-  } while (0)
-  switch (l) {
-    case 6: PDSP_TILE(6, 64); break;
-    case 7: PDSP_TILE(7, 32); break;
-    case 8: PDSP_TILE(8, 32); break;
-    case 9: PDSP_TILE(9, 16); break;
-    default: return fail(PDSP_ERR_UNSUPPORTED_SIZE, "unsupported tile-pass factor 2^%d", l);
-  }
-#undef PDSP_TILE
-#undef PDSP_TILE_IN
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
-constexpr int tile_width(int l) { return l == 6 ? 64 : (l == 9 ? 16 : 32); }
-
-// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27, f32, 16-byte aligned
-// planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
-// pass reads one pair and writes another, so input and output may alias each other.
-// `window` (real input only): applyWindow on the first pass's load; in_batch: distance between input rows.
-// The pass chain on one set of factor tables: `n` points per transform, np factors 2^l[i] with radix tables tw[i];
-// tshift = 1 when t.twa / t.twb belong to the 2n-point plan.  `first` = tile_pass_kernel's IN for the first pass
-// (im_in then carries the window table or nothing); in_batch = distance between input rows (real samples for
-// first >= 1).
-template <typename T>
-int tilepass_chain(const Tables<T> &t, long long n, int np, const int *l, typename pdsp::vec2<T>::type *const *tw,
-                   unsigned tshift, int first, long long batch, const T *re_in, const T *im_in, long long in_batch,
-                   T *re_out, T *im_out, T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s,
-                   const pdsp::TileGeom *fused_win = nullptr) {
-  auto with_window = [&](pdsp::TileGeom &g) {  // first = 5 / 6: the angle-addition tables and coefficients
-    if (fused_win) {
-      g.wa = fused_win->wa, g.wb = fused_win->wb, g.wstep = fused_win->wstep, g.we = fused_win->we;
-      g.k0 = fused_win->k0, g.k1 = fused_win->k1, g.k2 = fused_win->k2;
-    }
-  };
-  if (np == 2) {
-    const long long a = 1LL << l[0], b = 1LL << l[1];
-    pdsp::TileGeom g1{n, 1, (int)(b / tile_width(l[0])), 0, 0, b, b, 1u, in_batch, tshift};
-    with_window(g1);
-    if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
-    pdsp::TileGeom g2{n, 1, (int)(a / tile_width(l[1])), 0, 0, 0, a, 1u, n, tshift};
-    return tile_pass<T, false>(l[1], 0, (const T *)s1_re, (const T *)s1_im, re_out, im_out, tw[1], t, g2, scale, batch, s);
-  }
-  const long long a = 1LL << l[0], b = 1LL << l[1], c = 1LL << l[2];
-  pdsp::TileGeom g1{n, 1, (int)(b * c / tile_width(l[0])), 0, 0, b * c, b * c, 1u, in_batch, tshift};
-  with_window(g1);
-  pdsp::TileGeom g2{n, (int)a, (int)(c / tile_width(l[1])), b * c, c, c, a * c, (unsigned)a, n, tshift};
-  if (!(g_twopass & 2)) {
-    // the scratch planes between the first two passes tile-major (TileGeom::perm_*): the second pass reads its
-    // [B][TILE] tiles as contiguous chunks; pdsp_set_twopass bit 1 keeps them in natural order (A/B tests)
-    // log2 of the second pass's tile width (512-point columns: 32 on tile_cols512_kernel, which this mode implies)
-    const int lt = l[1] == 6 ? 6 : ((l[1] == 9 && !(sizeof(T) == 4 && t.tw8)) ? 4 : 5);
-    g1.perm_lc = l[2], g1.perm_lt = lt, g1.perm_b = (int)b;
-    g2.in_tile = b << lt, g2.in_stride = 1LL << lt;
-  }
-  if (int rc = tile_pass<T, true>(l[0], first, re_in, im_in, s1_re, s1_im, tw[0], t, g1, T(1), batch, s)) return rc;
-  if (int rc = tile_pass<T, true>(l[1], 0, (const T *)s1_re, (const T *)s1_im, s2_re, s2_im, tw[1], t, g2, T(1), batch, s))
-    return rc;
-  pdsp::TileGeom g3{n, 1, (int)(a * b / tile_width(l[2])), 0, 0, 0, a * b, 1u, n, tshift};
-  return tile_pass<T, false>(l[2], 0, (const T *)s2_re, (const T *)s2_im, re_out, im_out, tw[2], t, g3, scale, batch, s);
-}
-
-// Two or three tile passes (tile_pass_kernel's header): 2^15 <= N <= 2^27, f32, 16-byte aligned
-// planes.  s1 / s2: scratch plane pairs ((re, im) each); s2 is only used by the three-pass form.  Every
-// pass reads one pair and writes another, so input and output may alias each other.
-// `window` (real input only): applyWindow on the first pass's load; in_batch: distance between input rows.
-template <typename T>
-int tilepass_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out,
-                     T scale, T *s1_re, T *s1_im, T *s2_re, T *s2_im, hipStream_t s, const T *window = nullptr,
-                     long long in_batch = 0) {
-  const Tables<T> &t = tables<T>(plan);
-  const int first = im_in ? 0 : (window ? 2 : 1);
-  return tilepass_chain<T>(t, plan->n, t.tp_np, t.tp_l, t.tp_tw, 0u, first, batch, re_in, first == 2 ? window : im_in,
-                           in_batch ? in_batch : plan->n, re_out, im_out, scale, s1_re, s1_im, s2_re, s2_im, s);
-}
-
-// Do any of the output planes share bytes with any of the input planes?  Byte ranges, not pointer equality: an
-// output that starts one row into the input buffer overlaps it too.  The multi-pass paths use the output planes as
-// their first scratch pair only when this is false.
-template <typename T>
-bool planes_overlap(const T *re_in, const T *im_in, const T *re_out, const T *im_out, size_t plane_bytes) {
-  auto hit = [&](const T *a, const T *b) {
-    return a && b && (const char *)a < (const char *)b + plane_bytes && (const char *)b < (const char *)a + plane_bytes;
-  };
-  return hit(re_in, re_out) || hit(re_in, im_out) || hit(im_in, re_out) || hit(im_in, im_out);
-}
-
-template <typename T>
-int run_complex(const pdsp_plan *plan, long long batch, const T *re_in, const T *im_in, T *re_out, T *im_out, T scale,
-                hipStream_t s) {
-  if (int rc = check_plan_batch(plan, batch)) return rc;
-  if (batch == 0) return PDSP_OK;
-  if (!re_in || !re_out || !im_out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  const Tables<T> &t = tables<T>(plan);
-  if (!t.tw)
-    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit limit %d", plan->n, (int)(8 * sizeof(T)),
-                pdsp_max_size((int)sizeof(T)));
-  DeviceGuard g(plan->device);
-  PDSP_HIP_TRY(g.err);
-  // f64 Radix2Fft.forward rows (real input; f64 is the drop-in's default arithmetic) of N = 8192 and 16384: one
-  // N/2-point packed-real transform per row and the split to X[k], X[k + N/2] (fft_real_kernel) -- half the
-  // butterflies of the complex kernel on (x, 0), the same store streams, and N = 16384 stays in one pass.  These are
-  // the sizes where the complex f64 kernel is short of registers (N = 8192: fft_split2_kernel's LoadReal form
-  // spilled) or does not exist (N = 16384: four-step): tools/ab_real_packed.py --f64 on two boxes, N = 8192
-  // 4.93 -> 6.57 and 3.97 -> 5.69 TB/s, N = 16384 1.60 -> 5.18 and 1.57 -> 5.07; one frame through the host drop-in
-  // (tools/ab_single_frame_latency.py) 39.7 -> 36.2 us at 8192, but 47.3 -> 50.1 us at 16384 (one 512-thread
-  // workgroup is a longer critical path than three short launches), hence the batch threshold there.  Below 8192
-  // the same kernel measured +1 ... +9 % on one box and -9 ... +2 % on another (and 3-7 % slower for one frame): not
-  // robust, not dispatched, not built.  In f32 it measured 0.98 ... 1.01 of the complex kernels: not built either.
-  // Rows aligned to a sample pair.
-  if constexpr (sizeof(T) == 8) {
-    if (!im_in && g_real_packed && (plan->log2n == 13 || (plan->log2n == 14 && batch >= 8)) && t.tw_half && t.twr &&
-        ((uintptr_t)re_in & (2 * sizeof(T) - 1)) == 0) {
-      PDSP_HIP_TRY(launch_real<T>(plan->log2n - 1, re_in, re_out, im_out, scale, t.tw_half, t.twr, batch, s));
-      return PDSP_OK;
-    }
-  }
-  if constexpr (sizeof(T) == 4) {
-    // N = 2^15 / 2^16 out of place: ONE pass over HBM by 2 / 4 sibling workgroups per transform that share their
-    // XCD's L2 (fft_paired_kernel).  In place the siblings would overwrite each other's input: tile passes then.
-    // pdsp_set_twopass: any value but 1 keeps the tile passes (5: their current form) -- A/B tests.
-    if ((plan->log2n == 15 || plan->log2n == 16) && g_twopass == 1 && t.tw12 && t.tws4 && t.twa && t.twb &&
-        (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {
-      if (!planes_overlap(re_in, im_in, re_out, im_out, (size_t)batch * (size_t)plan->n * sizeof(T))) {
-        const int lp = plan->log2n - 14;
-        const long long blocks = ((batch + 7) / 8) * 8 * (1LL << lp);
-        if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
-        const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
-        const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
-#define PDSP_PAIRED(LP, REAL)                                                                                        \
-  hipLaunchKernelGGL((pdsp::fft_paired_kernel<T, LP, REAL>), dim3((unsigned)blocks), dim3(256), 0, s, re_in, im_in, re_out, \
-                     im_out, t.tw12, t.tws4, twa, twb, scale, batch, pdsp::PairedPacked{})
-        if (lp == 1) {
-          if (im_in) PDSP_PAIRED(1, false);
-          else PDSP_PAIRED(1, true);
-        } else {
-          if (im_in) PDSP_PAIRED(2, false);
-          else PDSP_PAIRED(2, true);
-        }
-#undef PDSP_PAIRED
-        PDSP_HIP_TRY(hipGetLastError());
-        return PDSP_OK;
-      }
-    }
-    // tile passes with balanced factors (two for 2^15..2^18, three for 2^19..2^27) where the tables exist and
-    // every plane is 16-byte aligned; pdsp_set_twopass(0) keeps round 1's four-step forms (A/B tests)
-    if (t.tp_np && (g_twopass & 1) &&
-        (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & 15) == 0) {
-      const size_t plane = (size_t)batch * (size_t)plan->n;
-      const bool aliased = planes_overlap(re_in, im_in, re_out, im_out, plane * sizeof(T));
-      // two passes: one scratch pair.  Three passes: the output planes double as the first scratch pair
-      // unless they share bytes with the input (equal pointers or a partial overlap).
-      const int pairs = t.tp_np == 2 ? 1 : (aliased ? 2 : 1);
-      StreamScratch mem(s);
-      PDSP_HIP_TRY(mem.alloc((size_t)pairs * 2 * plane * sizeof(T)));
-      T *const sc = (T *)mem.p;
-      if (t.tp_np == 2)
-        return tilepass_complex<T>(plan, batch, re_in, im_in, re_out, im_out, scale, sc, sc + plane, nullptr, nullptr, s);
-      T *s1_re = aliased ? sc + 2 * plane : re_out, *s1_im = aliased ? sc + 3 * plane : im_out;
-      return tilepass_complex<T>(plan, batch, re_in, im_in, re_out, im_out, scale, s1_re, s1_im, sc, sc + plane, s);
-    }
-  }
-  if (t.log2n1 > pdsp::kMaxLog2N1) {  // general four-step: the output planes double as the first scratch pair
-    const size_t plane = (size_t)batch * (size_t)plan->n;
-    const bool aliased = planes_overlap(re_in, im_in, re_out, im_out, plane * sizeof(T));
-    StreamScratch mem(s);
-    PDSP_HIP_TRY(mem.alloc((aliased ? 4 : 2) * plane * sizeof(T)));
-    T *const scratch = (T *)mem.p;
-    T *a_re = aliased ? scratch + 2 * plane : re_out, *a_im = aliased ? scratch + 3 * plane : im_out;
-    int rc = bigfft_rows<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, a_re, a_im, scratch, scratch + plane, s);
-    if (!rc) rc = bigfft_out<T, false>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
-    return rc;
-  }
-  if (t.log2n1 > 0) {  // beyond the single-pass limit: four-step through stream-ordered scratch planes
-    const size_t plane = (size_t)batch * (size_t)plan->n;
-    StreamScratch mem(s);
-    PDSP_HIP_TRY(mem.alloc(2 * plane * sizeof(T)));
-    T *const scratch = (T *)mem.p;
-    int rc = fourstep_ab<T>(plan, batch, re_in, im_in, nullptr, plan->n, plan->n, scratch, scratch + plane, s);
-    if (!rc) rc = fourstep_c<T, 0>(plan, batch, scratch, scratch + plane, re_out, im_out, scale, 0, 0, T(0), T(0), s);
-    return rc;
-  }
-  hipError_t e;
-  const bool planes16 =
-      (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & (4 * sizeof(T) - 1)) == 0;
-  if (plan->log2n >= 1 && plan->log2n <= 4 && g_staged_small && planes16) {  // 2 <= N <= 16: one thread per row
-    if (im_in) {
-      pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};
-      e = launch_tiny<T, false>(plan->log2n, ld, (const T *)nullptr, re_out, im_out, scale, 0, 0, T(0), T(0), batch, s);
-    } else {
-      pdsp::LoadReal<T> ld{re_in, plan->n};
-      e = launch_tiny<T, false>(plan->log2n, ld, (const T *)nullptr, re_out, im_out, scale, 0, 0, T(0), T(0), batch, s);
-    }
-    PDSP_HIP_TRY(e);
-    return PDSP_OK;
-  }
-  pdsp::StoreComplex<T> st{re_out, im_out, plan->n, scale};
-  // (f64 at N = 256: 69.6 KB of LDS per workgroup, the direct kernel measures 12 % faster)
-  if (plan->log2n >= 5 && plan->log2n <= (sizeof(T) == 4 ? 8 : 7) && g_staged_small &&
-      (((uintptr_t)re_in | (uintptr_t)im_in | (uintptr_t)re_out | (uintptr_t)im_out) & (4 * sizeof(T) - 1)) == 0) {
-    // small N: coalesced 16-byte I/O staged through LDS (fft_staged_kernel)
-    const long long blocks = (batch * plan->n + 4095) / 4096;
-#define PDSP_STAGED(L)                                                                                         \
-  do {                                                                                                         \
-    if (im_in) {                                                                                               \
-      pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};                                                          \
-      hipLaunchKernelGGL((pdsp::fft_staged_kernel<T, L, pdsp::LoadComplex<T>, pdsp::StoreComplex<T>>),          \
-                         dim3((unsigned)blocks), dim3(256), 0, s, ld, st, t.tw, batch);                        \
-    } else {                                                                                                   \
-      pdsp::LoadReal<T> ld{re_in, plan->n};                                                                    \
-      hipLaunchKernelGGL((pdsp::fft_staged_kernel<T, L, pdsp::LoadReal<T>, pdsp::StoreComplex<T>>),             \
-                         dim3((unsigned)blocks), dim3(256), 0, s, ld, st, t.tw, batch);                        \
-    }                                                                                                          \
-  } while (0)
-    switch (plan->log2n) {
-      case 5: PDSP_STAGED(5); break;
-      case 6: PDSP_STAGED(6); break;
-      case 7: PDSP_STAGED(7); break;
-      default: PDSP_STAGED(8); break;
-    }
-#undef PDSP_STAGED
-    PDSP_HIP_TRY(hipGetLastError());
-    return PDSP_OK;
-  }
-  const bool aligned16 = (((uintptr_t)re_in | (uintptr_t)im_in) & 15) == 0;
-  if (im_in) {
-    pdsp::LoadComplex<T> ld{re_in, im_in, plan->n};
-    e = launch_rows<T>(t, plan->log2n, ld, st, batch, s, aligned16);
-  } else {
-    pdsp::LoadReal<T> ld{re_in, plan->n};
-    e = launch_rows<T>(t, plan->log2n, ld, st, batch, s, aligned16);
-  }
-  PDSP_HIP_TRY(e);
-  return PDSP_OK;
-}
-
-// Interleaved complex rows (single-pass sizes): forward, or inverse = conj . forward . conj with 1/N.
-template <typename T>
-int run_interleaved(const pdsp_plan *plan, long long batch, const T *in, T *out, bool inverse, hipStream_t s) {
-  if (int rc = check_plan_batch(plan, batch)) return rc;
-  if (batch == 0) return PDSP_OK;
-  if (!in || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  if ((((uintptr_t)in | (uintptr_t)out) & (2 * sizeof(T) - 1)) != 0)
-    return fail(PDSP_ERR_BAD_ARG, "interleaved rows must be aligned to one (re, im) pair");
-  const Tables<T> &t = tables<T>(plan);
-  if (!t.tw || t.log2n1 > 0)
-    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "interleaved rows are single-pass only: FFT size %lld exceeds %d", plan->n,
-                1 << max_log2n<T>());
-  DeviceGuard g(plan->device);
-  PDSP_HIP_TRY(g.err);
-  const pdsp::cx<T> *zin = reinterpret_cast<const pdsp::cx<T> *>(in);
-  pdsp::cx<T> *zout = reinterpret_cast<pdsp::cx<T> *>(out);
-  if (inverse) {
-    pdsp::LoadInterleaved<T, true> ld{zin, plan->n};
-    pdsp::StoreInterleaved<T, true> st{zout, plan->n, T(1) / (T)plan->n};
-    PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s));
-  } else {
-    pdsp::LoadInterleaved<T, false> ld{zin, plan->n};
-    pdsp::StoreInterleaved<T, false> st{zout, plan->n, T(1)};
-    PDSP_HIP_TRY(launch_fft<T>(plan->log2n, ld, st, t.tw, batch, s));
-  }
-  return PDSP_OK;
-}
-
-int grid_for(long long total) {
-  long long b = (total + 255) / 256;
-  if (b > 2048) b = 2048;  // grid-stride the rest (256 CUs x 8)
-  if (b < 1) b = 1;
-  return (int)b;
 }
 
 int ensure_stage(pdsp_plan *plan, size_t bytes) {
@@ -1276,304 +471,6 @@ int require_device() {
   return PDSP_OK;
 }
 
-template <int OP>
-int launch_complex_op(long long count, const float *are, const float *aim, const float *bre, const float *bim,
-                      long long b_len, float sre, float sim, float *ore, float *oim, hipStream_t s) {
-  const bool binary = OP <= pdsp::kDiv;
-  const uintptr_t align = (uintptr_t)are | (uintptr_t)aim | (uintptr_t)ore | (uintptr_t)oim |
-                          (binary ? ((uintptr_t)bre | (uintptr_t)bim) : 0);
-  const bool vec4 = (align & 15) == 0 && count % 4 == 0 && (!binary || b_len % 4 == 0);
-  if (vec4)
-    hipLaunchKernelGGL((pdsp::complex_op_kernel<float, OP, 4>), dim3(grid_for(count / 4)), dim3(256), 0, s, are, aim,
-                       bre, bim, sre, sim, ore, oim, count, b_len);
-  else
-    hipLaunchKernelGGL((pdsp::complex_op_kernel<float, OP, 1>), dim3(grid_for(count)), dim3(256), 0, s, are, aim, bre,
-                       bim, sre, sim, ore, oim, count, b_len);
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
-
-template <typename T>
-int spectrum_impl(const pdsp_plan *plan, long long batch, const T *frames, long long frame_len, long long frame_stride,
-                  const T *window, int sides, T *amp_out, T *phase_out, int32_t *peak_idx_out, pdsp_peak32 *peaks_out,
-                  double sample_rate, hipStream_t stream) {
-  if (int rc = check_plan_batch(plan, batch)) return rc;
-  if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
-  // frame_stride < frame_len = overlapping frames of one signal (an STFT with hop = frame_stride): rows are only read
-  if (frame_len < 0 || frame_stride < 1) return fail(PDSP_ERR_BAD_ARG, "bad frame_len/frame_stride");
-  if (peaks_out && sample_rate <= 0)
-    return fail(PDSP_ERR_SAMPLE_RATE, "Sample rate must be positive, got %.17g", sample_rate);
-  if (batch == 0) return PDSP_OK;
-  if (!frames || (!amp_out && !peaks_out)) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  if ((phase_out || peak_idx_out) && !amp_out) return fail(PDSP_ERR_BAD_ARG, "phase/peak index output needs amp_out");
-  const Tables<T> &t = tables<T>(plan);
-  if (!t.tw && !t.tw_half)
-    return fail(PDSP_ERR_UNSUPPORTED_SIZE, "FFT size %lld exceeds the %d-bit limit %d", plan->n, (int)(8 * sizeof(T)),
-                pdsp_max_size((int)sizeof(T)));
-  DeviceGuard g(plan->device);
-  PDSP_HIP_TRY(g.err);
-  static_assert(sizeof(pdsp_peak32) == sizeof(pdsp::PeakRec), "peak record layout");
-  const long long n = plan->n;
-  const int bins = (int)(sides == PDSP_SIDES_ONE ? n / 2 + 1 : n);
-  const long long used = frame_len < n ? frame_len : n;
-  const T freq_scale = peaks_out ? (T)(sample_rate / (double)n) : T(0);
-  if (used == 0) {  // an empty frame is all zeros: amplitude 0, atan2(0, 0) = 0, peak 0
-    if (amp_out) PDSP_HIP_TRY(hipMemsetAsync(amp_out, 0, (size_t)batch * bins * sizeof(T), stream));
-    if (phase_out) PDSP_HIP_TRY(hipMemsetAsync(phase_out, 0, (size_t)batch * bins * sizeof(T), stream));
-    if (peak_idx_out) PDSP_HIP_TRY(hipMemsetAsync(peak_idx_out, 0, (size_t)batch * sizeof(int32_t), stream));
-    if (peaks_out) PDSP_HIP_TRY(hipMemsetAsync(peaks_out, 0, (size_t)batch * sizeof(pdsp_peak32), stream));
-    return PDSP_OK;
-  }
-  const T s_edge = T(1) / (T)n, s_mid = (sides == PDSP_SIDES_ONE ? T(2) : T(1)) / (T)n;
-  if constexpr (sizeof(T) == 4) {
-    // N beyond the single-pass limit, whole 16-byte aligned frames: the packed-real form on tile passes.
-    // z[m] = (x*w)[2m] + i (x*w)[2m+1] is read straight from the frame (and the window table) by the first
-    // pass; two (N <= 2^18) or three passes of the N/2-point transform (one pass of fft_split4_kernel at
-    // N = 2^15); split_amp_rows_kernel undoes the packing on the way to the amplitude (+ phase) rows.  HBM
-    // bytes per sample: 4+4, 4+4 (, 4+4), 4+2 = 22 (30) where the four-step forms on (x*w, 0) move 38 (70).  The four-step forms stay for partial /
-    // unaligned frames and f64.
-    if (t.log2n1 > 0 && t.hp_np && (g_twopass & 1) && used == n && (frame_stride & 3) == 0 &&
-        (((uintptr_t)frames | (uintptr_t)window) & 15) == 0) {
-      T *amp = amp_out, *ph = phase_out;
-      const long long m = n / 2;
-      const size_t plane = (size_t)batch * (size_t)m, rows = (size_t)batch * bins;
-      const size_t extra = (peaks_out && !amp ? rows : 0) + (peaks_out && !ph ? rows : 0);
-      StreamScratch mem(stream);
-      PDSP_HIP_TRY(mem.alloc((4 * plane + extra) * sizeof(T)));
-      T *const sc = (T *)mem.p;
-      if (peaks_out && !amp) amp = sc + 4 * plane;
-      if (peaks_out && !ph) ph = sc + 4 * plane + (amp_out ? 0 : rows);
-      // pass chain: frames -> s1 (-> s2) -> Z; two passes: Z = s2; three passes: Z = s1 again
-      T *const s1_re = sc, *const s1_im = sc + plane, *const s2_re = sc + 2 * plane, *const s2_im = sc + 3 * plane;
-      T *const z_re = t.hp_np == 2 ? s2_re : s1_re, *const z_im = t.hp_np == 2 ? s2_im : s1_im;
-      // a window that is one of the plan's own tables (pdsp_plan_window_f32) is known by kind: the cosine sum is
-      // then evaluated in the first pass instead of being read back (4 more bytes per sample).
-      // first = tile_pass_kernel's IN: 3 rect, 4 window table, 5 / 6 fused two- / three-term window
-      int first = window ? 4 : 3;
-      pdsp::TileGeom fw{};
-      int kind = -1;
-      for (int k = 0; k < 4; ++k)
-        if (window && window == t.win[k]) kind = k;
-      if (kind == PDSP_WIN_RECT) first = 3;  // createWindow("rect") is all ones
-      if (t.hp_win && g_fused_window && kind > PDSP_WIN_RECT) {
-        fw.wa = t.hp_win, fw.wb = fw.wa + 2 * t.hp_win_a, fw.wstep = fw.wb + 2 * 512, fw.we = fw.wstep + 2 * 8;
-        if (kind == PDSP_WIN_HANN) first = 5, fw.k0 = 0.5f, fw.k1 = -0.5f;
-        else if (kind == PDSP_WIN_HAMMING) first = 5, fw.k0 = 0.54f, fw.k1 = -0.46f;
-        else if (kind == PDSP_WIN_BLACKMAN) first = 6, fw.k0 = 0.42f - 0.08f, fw.k1 = -0.5f, fw.k2 = 2 * 0.08f;
-      }
-      if (plan->log2n == 15 && t.tws4 && t.tw12 && g_split16k) {
-        // N = 32768: the 16384-point transform is one pass of fft_split4_kernel (14 bytes per sample in all)
-        const pdsp::StoreComplex<T> st{z_re, z_im, m, T(1)};
-#define PDSP_SPLIT4_PACKED(W)                                                                                         \
-  hipLaunchKernelGGL((pdsp::fft_split4_kernel<T, 12, pdsp::LoadPackedFrames<T, W>, pdsp::StoreComplex<T>>),           \
-                     dim3((unsigned)batch), dim3(256), 0, stream,                                                     \
-                     pdsp::LoadPackedFrames<T, W>{frames, window, frame_stride, fw.wb, fw.we + 2 * 8, fw.we, fw.k0,   \
-                                                  fw.k1, fw.k2},                                                      \
-                     st, t.tw12, t.tws4, batch)
-        switch (first) {
-          case 3: PDSP_SPLIT4_PACKED(0); break;
-          case 4: PDSP_SPLIT4_PACKED(1); break;
-          case 5: PDSP_SPLIT4_PACKED(2); break;
-          default: PDSP_SPLIT4_PACKED(3); break;
-        }
-#undef PDSP_SPLIT4_PACKED
-        PDSP_HIP_TRY(hipGetLastError());
-      } else if (plan->log2n == 16 && g_twopass == 1 && t.tws4 && t.tw12) {
-        // N = 65536: the 32768-point transform in ONE pass by two sibling workgroups per frame that share an XCD's
-        // L2 (fft_paired_kernel, packed loader): 14 bytes per sample in all, where the two tile passes move 22
-        const long long blocks = ((batch + 7) / 8) * 8 * 2;
-        if (blocks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
-        const pdsp::PairedPacked pk{frame_stride, fw.wb, fw.we + 2 * 8, fw.we, fw.k0, fw.k1, fw.k2};
-        const pdsp::cx<T> *twa = reinterpret_cast<const pdsp::cx<T> *>(t.twa);
-        const pdsp::cx<T> *twb = reinterpret_cast<const pdsp::cx<T> *>(t.twb);
-#define PDSP_PAIRED_PACKED(PK)                                                                                       \
-  hipLaunchKernelGGL((pdsp::fft_paired_kernel<T, 1, false, PK>), dim3((unsigned)blocks), dim3(256), 0, stream, frames,   \
-                     first == 4 ? window : (const T *)nullptr, z_re, z_im, t.tw12, t.tws4, twa, twb, T(1), batch, pk)
-        switch (first) {
-          case 3: PDSP_PAIRED_PACKED(1); break;
-          case 4: PDSP_PAIRED_PACKED(2); break;
-          case 5: PDSP_PAIRED_PACKED(3); break;
-          default: PDSP_PAIRED_PACKED(4); break;
-        }
-#undef PDSP_PAIRED_PACKED
-        PDSP_HIP_TRY(hipGetLastError());
-      } else {
-        if (int rc = tilepass_chain<T>(t, m, t.hp_np, t.hp_l, t.hp_tw, 1u, first, batch, frames, first == 4 ? window : nullptr,
-                                       frame_stride, z_re, z_im, T(1), s1_re, s1_im, s2_re, s2_im, stream,
-                                       first >= 5 ? &fw : nullptr))
-          return rc;
-      }
-      const long long chunks = m / 2048;  // 256 lanes of four pairs each
-      if (batch * chunks > 0x7fffffffLL) return fail(PDSP_ERR_BAD_ARG, "batch too large: %lld", batch);
-      hipLaunchKernelGGL((pdsp::split_amp_rows_kernel<T>), dim3((unsigned)(batch * chunks)), dim3(256), 0, stream,
-                         (const T *)z_re, (const T *)z_im, amp, ph, reinterpret_cast<const pdsp::cx<T> *>(t.twa),
-                         reinterpret_cast<const pdsp::cx<T> *>(t.twb), (int)m, bins, s_edge, s_mid, batch);
-      PDSP_HIP_TRY(hipGetLastError());
-      if ((peaks_out || peak_idx_out) &&
-          launch_peaks<T>(amp, ph, bins, freq_scale, peak_idx_out, peaks_out, batch, stream) != hipSuccess)
-        return fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
-      return PDSP_OK;
-    }
-  }
-  // N beyond the single-pass limit: four-step on (x*w, 0), amplitude rows in the last pass.  (Not where the packed-real
-  // tables exist: f64 frames of N = 16384 are ONE 8192-point packed transform -- spectrum_packed_kernel<double, 13> --
-  // although the complex f64 transform of that size is a four-step one.  Round 2 sent them through the four-step
-  // path by this test's order.)
-  if (t.log2n1 > 0 && !t.tw_half) {
-    const bool big = t.log2n1 > pdsp::kMaxLog2N1;  // general path: two scratch pairs
-    T *amp = amp_out, *ph = phase_out;
-    const size_t plane = (size_t)batch * (size_t)n, rows = (size_t)batch * bins, planes = big ? 4 : 2;
-    const size_t extra = (peaks_out && !amp ? rows : 0) + (peaks_out && !ph ? rows : 0);
-    StreamScratch mem(stream);
-    PDSP_HIP_TRY(mem.alloc((planes * plane + extra) * sizeof(T)));
-    T *const scratch = (T *)mem.p;
-    if (peaks_out && !amp) amp = scratch + planes * plane;
-    if (peaks_out && !ph) ph = scratch + planes * plane + (amp_out ? 0 : rows);
-    const int nyq = (sides == PDSP_SIDES_ONE) ? (int)(n / 2) : -1;
-    int rc;
-    if (big) {
-      rc = bigfft_rows<T>(plan, batch, frames, nullptr, window, frame_stride, used, scratch + 2 * plane,
-                          scratch + 3 * plane, scratch, scratch + plane, stream);
-      if (!rc) rc = bigfft_out<T, true>(plan, batch, scratch, scratch + plane, amp, ph, T(1), bins, nyq, s_edge, s_mid, stream);
-    } else {
-      rc = fourstep_ab<T>(plan, batch, frames, nullptr, window, frame_stride, used, scratch, scratch + plane, stream);
-      if (!rc) rc = fourstep_c<T, 1>(plan, batch, scratch, scratch + plane, amp, ph, T(1), bins, nyq, s_edge, s_mid, stream);
-    }
-    if (!rc && (peaks_out || peak_idx_out) &&
-        launch_peaks<T>(amp, ph, bins, freq_scale, peak_idx_out, peaks_out, batch, stream) != hipSuccess)
-      rc = fail(PDSP_ERR_DEVICE, "peak kernel launch failed");
-    return rc;
-  }
-  constexpr uintptr_t kPairMask = 2 * sizeof(T) - 1;  // alignment of one (re, im) pair
-  if (t.tw_half) {
-    // packed-real path (N >= 64): N/2-point complex transform + Hermitian split (+ findPeak) fused with the store.
-    // fast variant: whole pair-aligned frames (and window), one-sided, no phase rows (config 4's shape); the
-    // general variant takes any frame length, stride and alignment of frames and window
-    const bool fast = ((uintptr_t)frames & kPairMask) == 0 && (frame_stride & 1) == 0 && used == n &&
-                      sides == PDSP_SIDES_ONE && phase_out == nullptr && ((uintptr_t)window & kPairMask) == 0;
-    // 64 <= N <= 512, amplitude only: contiguous frames staged in / amplitude rows staged out through LDS
-    // (f32 only: in f64 the two LDS regions take 102 KB, one workgroup per CU, and measure slower than the direct kernel)
-    if (sizeof(T) == 4 && fast && !peaks_out && !peak_idx_out && plan->log2n >= 6 && plan->log2n <= 9 && g_staged_small &&
-        frame_stride == n &&
-        ((uintptr_t)frames & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)window & (4 * sizeof(T) - 1)) == 0) {
-      const long long blocks = (batch * (n / 2) + 4095) / 4096;
-#define PDSP_SSTAGED(LM)                                                                                            \
-  do {                                                                                                              \
-    if (window)                                                                                                     \
-      hipLaunchKernelGGL((pdsp::spectrum_staged_kernel<T, LM, true>), dim3((unsigned)blocks), dim3(256), 0, stream,  \
-                         frames, window, t.tw_half, t.twr, amp_out, s_edge, s_mid, batch);                          \
-    else                                                                                                            \
-      hipLaunchKernelGGL((pdsp::spectrum_staged_kernel<T, LM, false>), dim3((unsigned)blocks), dim3(256), 0, stream, \
-                         frames, window, t.tw_half, t.twr, amp_out, s_edge, s_mid, batch);                          \
-  } while (0)
-      switch (plan->log2n - 1) {
-        case 5: PDSP_SSTAGED(5); break;
-        case 6: PDSP_SSTAGED(6); break;
-        case 7: PDSP_SSTAGED(7); break;
-        default: PDSP_SSTAGED(8); break;
-      }
-#undef PDSP_SSTAGED
-      PDSP_HIP_TRY(hipGetLastError());
-      return PDSP_OK;
-    }
-    bool launched = false;
-    // A window that is one of the PLAN'S OWN tables (pdsp_plan_window_f32) is known by kind: the kernels
-    // that can (whole f32 frames, N = 1024 ... 16384) then evaluate the cosine sum in registers.
-    // wmode: 0 rect, 1 table, 2 / 3 fused two- / three-term cosine sum.
-    pdsp::WinFused wf{nullptr, nullptr, 0.f, 0.f, 0.f, 1.f};
-    int wmode = window ? 1 : 0;
-    if constexpr (sizeof(T) == 4) {
-      int kind = -1;  // -1: caller's table
-      for (int k = 0; k < 4; ++k)
-        if (window && window == t.win[k]) kind = k;
-      if (kind == PDSP_WIN_RECT) wmode = 0;  // createWindow("rect") is all ones
-      if (t.wf_base && g_fused_window && fast) {
-        wf.base = t.wf_base, wf.step = t.wf_step;
-        if (kind == PDSP_WIN_HANN) wmode = 2, wf.k0 = 0.5f, wf.k1 = -0.5f;
-        else if (kind == PDSP_WIN_HAMMING) wmode = 2, wf.k0 = 0.54f, wf.k1 = -0.46f;
-        else if (kind == PDSP_WIN_BLACKMAN) wmode = 3, wf.k0 = 0.42f - 0.08f, wf.k1 = -0.5f, wf.k2 = 2 * 0.08f;
-        if (wmode >= 2) {  // the kernels take the fused coefficients pre-scaled by s_mid / 2 (a power of two: exact)
-          const float g = 0.5f * (float)s_mid;
-          wf.k0 *= g, wf.k1 *= g, wf.k2 *= g;
-          wf.edge_ratio = (float)(s_edge / s_mid);
-        }
-      }
-    }
-    if constexpr (sizeof(T) == 4) {
-      // N = 16384: two 4096-point sub-transforms per 256-thread workgroup (3 frames per CU instead of 2),
-      // decimation in frequency on top (spectrum_dif16k_kernel).  A window that is one of the PLAN'S OWN
-      // tables (pdsp_plan_window_f32) is known by kind, and createWindow is fused into the kernel: the
-      // reference's windows are cosine sums (fourier.ts:14-52), evaluated in registers instead of being
-      // read back, 64 KB per frame, from L2.  Any other window pointer is read as a table.
-      if (fast && plan->log2n == 14 && g_split16k && t.wf_base) {
-        pdsp::PeakRec *pk = reinterpret_cast<pdsp::PeakRec *>(peaks_out);
-        const int mode = wmode;
-#define PDSP_DIF(W, P)                                                                                              \
-  hipLaunchKernelGGL((pdsp::spectrum_dif16k_kernel<T, W, P>), dim3((unsigned)batch), dim3(256), 0, stream, frames,  \
-                     window, wf, frame_stride, t.tw12, t.twr, amp_out, s_edge, s_mid, pk, freq_scale, batch)
-#define PDSP_DIF_P(W)    \
-  do {                   \
-    if (pk) PDSP_DIF(W, true); \
-    else PDSP_DIF(W, false);   \
-  } while (0)
-        switch (mode) {
-          case 0: PDSP_DIF_P(0); break;
-          case 1: PDSP_DIF_P(1); break;
-          case 2: PDSP_DIF_P(2); break;
-          default: PDSP_DIF_P(3); break;
-        }
-#undef PDSP_DIF_P
-#undef PDSP_DIF
-        PDSP_HIP_TRY(hipGetLastError());
-        launched = true;  // a requested peak-index array is filled by the common tail below
-      }
-    }
-    if (!launched)
-      PDSP_HIP_TRY(launch_packed<T>(plan->log2n - 1, fast, frames, wmode == 0 ? (const T *)nullptr : window,
-                                    (wmode >= 2 && plan->log2n == 14) ? 1 : wmode, wf, used, frame_stride, t.tw_half, t.twr,
-                                    amp_out, phase_out, sides == PDSP_SIDES_TWO ? 1 : 0, s_edge, s_mid,
-                                    reinterpret_cast<pdsp::PeakRec *>(peaks_out), freq_scale, batch, stream));
-  } else {
-    // complex kernel on (x, 0) for N < 64 (the sizes without packed-real tables); peaks come from the stored rows
-    if (!t.tw || plan->log2n > 5) return fail(PDSP_ERR_UNSUPPORTED_SIZE, "no spectrum tables for size %lld", plan->n);
-    if (plan->log2n >= 1 && plan->log2n <= 5 && g_staged_small && used == n && frame_stride == n && amp_out &&
-        !phase_out && !peaks_out && ((uintptr_t)frames & (4 * sizeof(T) - 1)) == 0) {
-      // 2 <= N <= 32, whole contiguous frames, amplitude only: one thread per frame, chunk staged through LDS
-      pdsp::LoadReal<T> ld{frames, n};
-      PDSP_HIP_TRY((launch_tiny<T, true>(plan->log2n, ld, window, amp_out, (T *)nullptr, T(1), bins,
-                                         sides == PDSP_SIDES_ONE ? (int)(n / 2) : -1, s_edge, s_mid, batch, stream)));
-      if (peak_idx_out)
-        PDSP_HIP_TRY(launch_peaks<T>(amp_out, (const T *)nullptr, bins, T(0), peak_idx_out, nullptr, batch, stream));
-      return PDSP_OK;
-    }
-    T *amp = amp_out, *ph = phase_out;
-    const size_t row_bytes = (size_t)batch * bins * sizeof(T);
-    StreamScratch tmp_amp(stream), tmp_ph(stream);  // peaks-only output: the rows live in scratch
-    if (peaks_out && !amp) {
-      PDSP_HIP_TRY(tmp_amp.alloc(row_bytes));
-      amp = (T *)tmp_amp.p;
-    }
-    if (peaks_out && !ph) {
-      PDSP_HIP_TRY(tmp_ph.alloc(row_bytes));
-      ph = (T *)tmp_ph.p;
-    }
-    pdsp::StoreAmplitude<T> st{amp, ph, bins,
-                               // scaleAmplitudeOneSided: `nyquist = size % 2 === 0 ? size/2 : -1`; N = 1 is odd
-                               (sides == PDSP_SIDES_ONE && n % 2 == 0) ? (int)(n / 2) : -1, s_edge, s_mid};
-    if (window) {
-      pdsp::LoadFrameWindowed<T, true> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft_small<T>(plan->log2n, ld, st, t.tw, batch, stream));
-    } else {
-      pdsp::LoadFrameWindowed<T, false> ld{frames, window, used, frame_stride};
-      PDSP_HIP_TRY(launch_fft_small<T>(plan->log2n, ld, st, t.tw, batch, stream));
-    }
-    if (peaks_out) PDSP_HIP_TRY(launch_peaks<T>(amp, ph, bins, freq_scale, nullptr, peaks_out, batch, stream));
-  }
-  if (peak_idx_out)
-    PDSP_HIP_TRY(launch_peaks<T>(amp_out, (const T *)nullptr, bins, T(0), peak_idx_out, nullptr, batch, stream));
-  return PDSP_OK;
-}
-
 // ---- chunked host calls -------------------------------------------------------------------------------------
 // A batched host-f64 call moves every sample through the CPU twice (the caller's f64 rows <-> pinned staging), over
 // PCIe twice, and through a kernel that needs a few percent of that time.  As ONE stage -> copy -> launch -> copy ->
@@ -1769,26 +666,6 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
   PDSP_HIP_TRY(hipStreamSynchronize(s));
   stage_to_rows<T>(re_out, h_ore, cnt);
   stage_to_rows<T>(im_out, h_oim, cnt);
-  return PDSP_OK;
-}
-
-template <typename T>
-int apply_window_dev(long long batch, long long n, const T *in, const T *window, T *out, hipStream_t s) {
-  const long long total = batch * n;
-  if (total == 0) return PDSP_OK;
-  if (!in || !window || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  hipLaunchKernelGGL((pdsp::apply_window_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, in, window, out, total, n);
-  PDSP_HIP_TRY(hipGetLastError());
-  return PDSP_OK;
-}
-
-template <typename T, bool PHASE>
-int polar_dev(long long count, const T *re, const T *im, T *out, hipStream_t s) {
-  if (count < 0) return fail(PDSP_ERR_BAD_ARG, "negative size");
-  if (count == 0) return PDSP_OK;
-  if (!re || !im || !out) return fail(PDSP_ERR_BAD_ARG, "null buffer");
-  hipLaunchKernelGGL((pdsp::polar_kernel<T, PHASE>), dim3(grid_for(count)), dim3(256), 0, s, re, im, out, count);
-  PDSP_HIP_TRY(hipGetLastError());
   return PDSP_OK;
 }
 
@@ -2229,15 +1106,7 @@ int pdsp_complex_op_f32(int op, long long count, const float *a_re, const float 
   }
   hipStream_t s = (hipStream_t)stream;
   const float sr = (float)s_re, si = (float)s_im;
-  switch (op) {
-    case PDSP_CX_ADD: return launch_complex_op<pdsp::kAdd>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
-    case PDSP_CX_SUB: return launch_complex_op<pdsp::kSub>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
-    case PDSP_CX_MUL: return launch_complex_op<pdsp::kMul>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
-    case PDSP_CX_DIV: return launch_complex_op<pdsp::kDiv>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
-    case PDSP_CX_CONJ: return launch_complex_op<pdsp::kConj>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
-    case PDSP_CX_SCALE: return launch_complex_op<pdsp::kScale>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
-    default: return launch_complex_op<pdsp::kMulScalar>(count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
-  }
+  return complex_op_f32(op, count, a_re, a_im, b_re, b_im, b_len, sr, si, out_re, out_im, s);
 }
 
 /* ---- fused spectrum: peaks ---------------------------------------------------- */

@@ -62,15 +62,27 @@ def waves_per_simd(vgprs: int) -> int:
 
 
 def kernels(lib: str = DEFAULT_LIB):
+    """One record per kernel NAME.  The library is linked from several translation units, each with a code object of
+    its own in .hip_fatbin (one offload bundle per unit, concatenated); a template kernel that two units instantiate
+    appears in both -- the same source compiled with the same flags -- and is listed once, with the LARGER of any
+    resource figure should they ever differ (`units` says how many code objects carry it)."""
+    MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+    notes = ""
     with tempfile.TemporaryDirectory(prefix="pdsp_kres_") as td:
-        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        fat = os.path.join(td, "fat.bin")
         # (an explicit output file: with the input alone llvm-objcopy rewrites the library IN PLACE)
         subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", lib,
                         os.path.join(td, "copy.so")], check=True)
-        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
-                               check=True).stdout
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for i, a in enumerate(starts):
+            one, co = os.path.join(td, f"bundle{i}.bin"), os.path.join(td, f"dev{i}.co")
+            with open(one, "wb") as f:
+                f.write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={one}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+            notes += subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
+                                    check=True).stdout + "\n"
     recs, cur = [], None
     for line in notes.splitlines():
         m = re.match(r"\s*(?:- )?\.(\w+):\s+(\S.*)$", line)
@@ -87,6 +99,13 @@ def kernels(lib: str = DEFAULT_LIB):
         elif key == "name":
             cur["mangled"] = val
     recs = [r for r in recs if "mangled" in r]
+    merged = {}
+    for r in recs:
+        m = merged.setdefault(r["mangled"], dict(r, units=0))
+        m["units"] += 1
+        for k in FIELDS:
+            m[k] = max(m.get(k, 0), r.get(k, 0))
+    recs = list(merged.values())
     for r, d in zip(recs, demangle([r["mangled"] for r in recs])):
         r["kernel"] = short_name(d)
         wg = r.get("max_flat_workgroup_size", 256)
