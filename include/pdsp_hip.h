@@ -321,6 +321,15 @@ PDSP_API int pdsp_spectrum_rows_host_f64(const double *const *rows, long long ba
                                          double *freq_out, double *amp_out, double *phase_out,
                                          pdsp_peak *peak_out, long long *bins_out);
 
+/* The same for frames held as 32-bit floats (Float32Array: what Web Audio, decoders and capture APIs hand a JS
+ * caller; `ArrayLike<number>` in the reference's signature): rows[b] points at `len` floats.  The samples are widened
+ * exactly (float -> double is exact) where the call computes in f64, and taken as they are in f32 mode, so the
+ * results equal those of the f64 entry points on the widened frames bit for bit; outputs stay f64. */
+PDSP_API int pdsp_spectrum_rows_host_f32in(const float *const *rows, long long batch, long long len,
+                                           double sample_rate, long long fft_size, int window, int sides,
+                                           double *freq_out, double *amp_out, double *phase_out,
+                                           pdsp_peak *peak_out, long long *bins_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,7 @@ def _load() -> C.CDLL:
         "pdsp_spectrum_host_f64": ([dp, ll, dbl, ll, i32, i32, dp, dp, dp, C.POINTER(Peak), C.POINTER(ll)], i32),
         "pdsp_spectrum_batch_host_f64": ([dp, ll, ll, dbl, ll, i32, i32, dp, dp, dp, C.POINTER(Peak), C.POINTER(ll)], i32),
         "pdsp_spectrum_rows_host_f64": ([C.POINTER(dp), ll, ll, dbl, ll, i32, i32, dp, dp, dp, C.POINTER(Peak), C.POINTER(ll)], i32),
+        "pdsp_spectrum_rows_host_f32in": ([C.POINTER(C.POINTER(C.c_float)), ll, ll, dbl, ll, i32, i32, dp, dp, dp, C.POINTER(Peak), C.POINTER(ll)], i32),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

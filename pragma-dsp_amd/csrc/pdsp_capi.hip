@@ -716,12 +716,42 @@ inline void host_peaks(const double *freq, const double *amp_out, const double *
   }
 }
 
-// Frame b starts at row_ptrs[b] when row_ptrs is given (pdsp_spectrum_rows_host_f64), else at samples + b * len.
+// Where the frames of a host spectrum call lie: contiguous f64 (pdsp_spectrum_batch_host_f64), one pointer per frame
+// in f64 (pdsp_spectrum_rows_host_f64) or in f32 (pdsp_spectrum_rows_host_f32in: Float32Array audio frames).
+struct FrameSource {
+  const double *samples = nullptr;
+  const double *const *rows64 = nullptr;
+  const float *const *rows32 = nullptr;
+  long long len = 0;
+  size_t frame_bytes() const { return (size_t)len * (rows32 ? sizeof(float) : sizeof(double)); }
+  const void *frame(long long b) const {
+    if (rows32) return rows32[b];
+    return rows64 ? rows64[b] : samples + (size_t)b * (size_t)len;
+  }
+  // the first `used` samples of frame b into staging of precision T
+  template <typename T>
+  void stage(T *dst, long long b, size_t used) const {
+    if (rows32) {
+      const float *src = rows32[b];
+      if constexpr (sizeof(T) == sizeof(float)) std::memcpy(dst, src, used * sizeof(float));
+      else
+        for (size_t i = 0; i < used; ++i) dst[i] = (T)src[i];
+    } else {
+      rows_to_stage<T>(dst, (const double *)frame(b), used);
+    }
+  }
+  bool overlaps(const void *out, size_t out_bytes, long long batch) const {
+    if (!rows64 && !rows32) return host_ranges_overlap(samples, (size_t)batch * frame_bytes(), out, out_bytes);
+    for (long long b = 0; b < batch; ++b)
+      if (host_ranges_overlap(frame(b), frame_bytes(), out, out_bytes)) return true;
+    return false;
+  }
+};
+
 template <typename T>
-int spectrum_host_t(pdsp_plan *plan, const double *samples, const double *const *row_ptrs, long long len, int window,
-                    int sides, double *amp_out, double *phase_out, long long batch, const double *freq,
-                    pdsp_peak *peak_out) {
-  auto frame = [&](long long b) { return row_ptrs ? row_ptrs[b] : samples + (size_t)b * (size_t)len; };
+int spectrum_host_t(pdsp_plan *plan, const FrameSource &in, int window, int sides, double *amp_out, double *phase_out,
+                    long long batch, const double *freq, pdsp_peak *peak_out) {
+  const long long len = in.len;
   const long long n = plan->n;
   const long long bins = sides == PDSP_SIDES_ONE ? n / 2 + 1 : n;
   const long long used = len < n ? len : n;
@@ -730,15 +760,8 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, const double *const 
     const size_t frame_bytes = (size_t)n * sizeof(T);
     const long long per_chunk = (long long)(kChunkInBytes / frame_bytes);
     const int workers = host_workers(tables<T>(plan).log2n1 > 0 && !tables<T>(plan).tw_half);  // packed-real frames: one pass
-    const size_t in_b = (size_t)batch * (size_t)(len > 0 ? len : 1) * sizeof(double), out_b = (size_t)batch * (size_t)bins * sizeof(double);
-    bool overlap = false;
-    if (row_ptrs) {
-      for (long long b = 0; b < batch && !overlap; ++b)
-        overlap = host_ranges_overlap(row_ptrs[b], (size_t)len * sizeof(double), amp_out, out_b) ||
-                  host_ranges_overlap(row_ptrs[b], (size_t)len * sizeof(double), phase_out, out_b);
-    } else {
-      overlap = host_ranges_overlap(samples, in_b, amp_out, out_b) || host_ranges_overlap(samples, in_b, phase_out, out_b);
-    }
+    const size_t out_b = (size_t)batch * (size_t)bins * sizeof(double);
+    const bool overlap = len > 0 && (in.overlaps(amp_out, out_b, batch) || in.overlaps(phase_out, out_b, batch));
     if (workers >= 2 && per_chunk >= 1 && batch >= 2 * per_chunk && len > 0 &&
         (size_t)batch * (size_t)(n + 2 * bins) * sizeof(T) >= kChunkedMinBytes && !overlap) {
       const T *d_window = nullptr;
@@ -756,7 +779,7 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, const double *const 
         T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
         for (long long b = 0; b < job.count; ++b) {
           T *dst = h + (size_t)b * (size_t)n;
-          rows_to_stage<T>(dst, frame(job.first + b), (size_t)used);
+          in.stage<T>(dst, job.first + b, (size_t)used);
           if (used < n) std::memset(dst + used, 0, (size_t)(n - used) * sizeof(T));
         }
         const size_t rows = (size_t)job.count * (size_t)bins;
@@ -781,9 +804,8 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, const double *const 
   if (int rc = ensure_stage(plan, total * sizeof(T))) return rc;
   T *h = (T *)plan->h_stage, *d = (T *)plan->d_stage;
   for (long long b = 0; b < batch; ++b) {
-    const double *src = frame(b);
     T *dst = h + (size_t)b * (size_t)n;
-    for (long long i = 0; i < used; ++i) dst[i] = (T)src[i];
+    if (used > 0) in.stage<T>(dst, b, (size_t)used);
     for (long long i = used; i < n; ++i) dst[i] = T(0);
   }
   const T *d_window = nullptr;
@@ -804,9 +826,9 @@ int spectrum_host_t(pdsp_plan *plan, const double *samples, const double *const 
   return PDSP_OK;
 }
 
-int spectrum_frames_host(const double *samples, const double *const *rows, long long batch, long long len,
-                         double sample_rate, long long fft_size, int window, int sides, double *freq_out,
-                         double *amp_out, double *phase_out, pdsp_peak *peak_out, long long *bins_out);
+int spectrum_frames_host(const FrameSource &in, long long batch, double sample_rate, long long fft_size, int window,
+                         int sides, double *freq_out, double *amp_out, double *phase_out, pdsp_peak *peak_out,
+                         long long *bins_out);
 
 }  // namespace
 
@@ -1193,8 +1215,12 @@ int pdsp_spectrum_host_f64(const double *samples, long long len, double sample_r
 int pdsp_spectrum_batch_host_f64(const double *samples, long long batch, long long len, double sample_rate,
                                  long long fft_size, int window, int sides, double *freq_out, double *amp_out,
                                  double *phase_out, pdsp_peak *peak_out, long long *bins_out) {
-  return spectrum_frames_host(samples, nullptr, batch, len, sample_rate, fft_size, window, sides, freq_out, amp_out,
-                              phase_out, peak_out, bins_out);
+  if (len > 0 && batch > 0 && !samples) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+  FrameSource in;
+  in.samples = samples;
+  in.len = len;
+  return spectrum_frames_host(in, batch, sample_rate, fft_size, window, sides, freq_out, amp_out, phase_out, peak_out,
+                              bins_out);
 }
 
 int pdsp_spectrum_rows_host_f64(const double *const *rows, long long batch, long long len, double sample_rate,
@@ -1205,19 +1231,38 @@ int pdsp_spectrum_rows_host_f64(const double *const *rows, long long batch, long
     for (long long b = 0; b < batch; ++b)
       if (!rows[b]) return fail(PDSP_ERR_BAD_ARG, "bad samples");
   }
-  return spectrum_frames_host(nullptr, len > 0 ? rows : nullptr, batch, len, sample_rate, fft_size, window, sides,
-                              freq_out, amp_out, phase_out, peak_out, bins_out);
+  FrameSource in;
+  in.rows64 = len > 0 ? rows : nullptr;
+  in.len = len;
+  return spectrum_frames_host(in, batch, sample_rate, fft_size, window, sides, freq_out, amp_out, phase_out, peak_out,
+                              bins_out);
+}
+
+int pdsp_spectrum_rows_host_f32in(const float *const *rows, long long batch, long long len, double sample_rate,
+                                  long long fft_size, int window, int sides, double *freq_out, double *amp_out,
+                                  double *phase_out, pdsp_peak *peak_out, long long *bins_out) {
+  if (batch > 0 && len > 0) {
+    if (!rows) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+    for (long long b = 0; b < batch; ++b)
+      if (!rows[b]) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+  }
+  FrameSource in;
+  in.rows32 = len > 0 ? rows : nullptr;
+  in.len = len;
+  return spectrum_frames_host(in, batch, sample_rate, fft_size, window, sides, freq_out, amp_out, phase_out, peak_out,
+                              bins_out);
 }
 
 }  // extern "C"
 
 namespace {
 
-int spectrum_frames_host(const double *samples, const double *const *rows, long long batch, long long len,
-                         double sample_rate, long long fft_size, int window, int sides, double *freq_out,
-                         double *amp_out, double *phase_out, pdsp_peak *peak_out, long long *bins_out) {
+int spectrum_frames_host(const FrameSource &in, long long batch, double sample_rate, long long fft_size, int window,
+                         int sides, double *freq_out, double *amp_out, double *phase_out, pdsp_peak *peak_out,
+                         long long *bins_out) {
+  const long long len = in.len;
   if (batch < 0) return fail(PDSP_ERR_BAD_ARG, "batch must be >= 0, got %lld", batch);
-  if (len < 0 || (len > 0 && batch > 0 && !samples && !rows)) return fail(PDSP_ERR_BAD_ARG, "bad samples");
+  if (len < 0) return fail(PDSP_ERR_BAD_ARG, "bad samples");
   if (sides != PDSP_SIDES_ONE && sides != PDSP_SIDES_TWO) return fail(PDSP_ERR_BAD_ARG, "bad sides %d", sides);
   // Error order of spectrum.ts:113-132: FFT ctor (power of two) -> createWindow
   // (type; N == 1 returns before the type switch) -> ... -> binFrequencies (rate).
@@ -1239,12 +1284,10 @@ int spectrum_frames_host(const double *samples, const double *const *rows, long 
   if (bins_out) *bins_out = bins;
   if (batch == 0) return PDSP_OK;
   const bool f64 = host_precision() == 64 && (plan->t64.tw_half || plan->t64.tw);
-  static const double kNoSample = 0.0;  // len == 0: every frame is all zero padding
-  const double *src = len > 0 ? samples : &kNoSample;
+  // (len == 0: every frame is all zero padding; no frame is read)
   // findPeak runs on the host over the f64 amplitudes (host_peaks), inside the call's staging loop
-  const int rc_run =
-      f64 ? spectrum_host_t<double>(plan, src, rows, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out)
-          : spectrum_host_t<float>(plan, src, rows, len, window, sides, amp_out, phase_out, batch, freq_out, peak_out);
+  const int rc_run = f64 ? spectrum_host_t<double>(plan, in, window, sides, amp_out, phase_out, batch, freq_out, peak_out)
+                         : spectrum_host_t<float>(plan, in, window, sides, amp_out, phase_out, batch, freq_out, peak_out);
   trim_stage(plan);
   return rc_run;
 }

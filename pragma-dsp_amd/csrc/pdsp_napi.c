@@ -64,6 +64,26 @@ static int f64_array(napi_env env, napi_value v, double **data, size_t *len) {
   return 1;
 }
 
+/* Float64Array or Float32Array -> (data, length, is_f32); anything else throws a TypeError. */
+static int f64_or_f32_array(napi_env env, napi_value v, void **data, size_t *len, int *is_f32) {
+  bool is_ta = false;
+  napi_typedarray_type tt;
+  void *p = NULL;
+  size_t n = 0;
+  *data = NULL;
+  *len = 0;
+  if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta ||
+      napi_get_typedarray_info(env, v, &tt, &n, &p, NULL, NULL) != napi_ok ||
+      (tt != napi_float64_array && tt != napi_float32_array)) {
+    napi_throw_type_error(env, NULL, "pdsp_napi: expected a Float64Array or a Float32Array");
+    return 0;
+  }
+  *data = p;
+  *len = n;
+  *is_f32 = tt == napi_float32_array;
+  return 1;
+}
+
 static int get_i64(napi_env env, napi_value v, int64_t *out) {
   if (napi_get_value_int64(env, v, out) != napi_ok) {
     napi_throw_type_error(env, NULL, "pdsp_napi: expected a number");
@@ -384,8 +404,9 @@ static napi_value SpectrumBatch(napi_env env, napi_callback_info info) {
 }
 
 /* spectrumRows(frames, start, batch, frameLen, sampleRate, fftSizeOrMinus1, window, sides, freq, amp, phase, peaks)
- * frames: a JS array whose elements start .. start+batch-1 are Float64Arrays of frameLen samples each -- taken where
- * they lie (pdsp_spectrum_rows_host_f64), not flattened; outputs as spectrumBatch. */
+ * frames: a JS array whose elements start .. start+batch-1 are all Float64Arrays or all Float32Arrays of frameLen
+ * samples each -- taken where they lie (pdsp_spectrum_rows_host_f64 / _f32in), not flattened; outputs as
+ * spectrumBatch. */
 static napi_value SpectrumRows(napi_env env, napi_callback_info info) {
   napi_value argv[12];
   if (!get_args(env, info, 12, argv)) return NULL;
@@ -415,7 +436,7 @@ static napi_value SpectrumRows(napi_env env, napi_callback_info info) {
     napi_throw_error(env, NULL, "pdsp_napi: spectrumRows outputs too small");
     return NULL;
   }
-  const double **rows = (const double **)malloc(sizeof(double *) * (size_t)(batch > 0 ? batch : 1));
+  const void **rows = (const void **)malloc(sizeof(void *) * (size_t)(batch > 0 ? batch : 1));
   pdsp_peak *recs = (pdsp_peak *)malloc(sizeof(pdsp_peak) * (size_t)(batch > 0 ? batch : 1));
   if (!rows || !recs) {
     free(rows);
@@ -424,16 +445,23 @@ static napi_value SpectrumRows(napi_env env, napi_callback_info info) {
     return NULL;
   }
   static double dummy = 0.0;
+  int run_f32 = -1; /* the run's element type: every frame a Float64Array, or every frame a Float32Array */
   for (int64_t b = 0; b < batch; ++b) {
     napi_handle_scope scope;
     napi_value el;
-    double *p = NULL;
+    void *p = NULL;
     size_t plen = 0;
+    int f32 = 0;
     int ok = napi_open_handle_scope(env, &scope) == napi_ok;
     if (ok) {
-      ok = napi_get_element(env, argv[0], (uint32_t)(start + b), &el) == napi_ok && f64_array(env, el, &p, &plen);
+      ok = napi_get_element(env, argv[0], (uint32_t)(start + b), &el) == napi_ok &&
+           f64_or_f32_array(env, el, &p, &plen, &f32);
       if (ok && (int64_t)plen != len) {
         napi_throw_error(env, NULL, "pdsp_napi: spectrumRows frames must all have frameLen samples");
+        ok = 0;
+      }
+      if (ok && run_f32 >= 0 && run_f32 != f32) {
+        napi_throw_type_error(env, NULL, "pdsp_napi: spectrumRows frames must all be of one typed-array kind");
         ok = 0;
       }
       napi_close_handle_scope(env, scope);
@@ -445,10 +473,14 @@ static napi_value SpectrumRows(napi_env env, napi_callback_info info) {
       free(recs);
       return NULL;
     }
-    rows[b] = p ? p : &dummy; /* a zero-length Float64Array has no data pointer */
+    run_f32 = f32;
+    rows[b] = p ? p : (void *)&dummy; /* a zero-length typed array has no data pointer */
   }
-  const int rc = pdsp_spectrum_rows_host_f64(rows, batch, len, rate, fft_size, (int)window, (int)sides, freq, amp, ph, recs,
-                                             NULL);
+  const int rc = run_f32 == 1
+                     ? pdsp_spectrum_rows_host_f32in((const float *const *)rows, batch, len, rate, fft_size, (int)window,
+                                                     (int)sides, freq, amp, ph, recs, NULL)
+                     : pdsp_spectrum_rows_host_f64((const double *const *)rows, batch, len, rate, fft_size, (int)window,
+                                                   (int)sides, freq, amp, ph, recs, NULL);
   if (rc == PDSP_OK)
     for (int64_t b = 0; b < batch; ++b) {
       pk[4 * b + 0] = (double)recs[b].index;

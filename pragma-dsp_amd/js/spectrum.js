@@ -64,10 +64,12 @@ function spectrumBatch(frames, options) {
     const amplitude = new Float64Array(batch * bins);
     const phase = new Float64Array(batch * bins);
     const peaks = new Float64Array(4 * batch);
-    // a run of Float64Arrays is read where it lies (one pointer per frame); anything else -- plain arrays,
-    // Float32Arrays, holes read as 0 -- is flattened to f64 first
-    let inPlace = true;
-    for (let b = start; b < end && inPlace; b++) inPlace = frames[b] instanceof Float64Array;
+    // a run of Float64Arrays -- or of Float32Arrays, the usual form of audio frames -- is read where it lies (one
+    // pointer per frame); anything else -- plain arrays, other typed arrays, mixed kinds, holes read as 0 -- is
+    // flattened to f64 first
+    const Kind = frames[start] instanceof Float32Array ? Float32Array : Float64Array;
+    let inPlace = Array.isArray(frames);
+    for (let b = start; b < end && inPlace; b++) inPlace = frames[b] instanceof Kind;
     if (inPlace) {
       native.spectrumRows(frames, start, batch, len, sampleRate, targetSize, id === undefined ? 0 : id, one ? 0 : 1,
         frequencies, amplitude, phase, peaks);

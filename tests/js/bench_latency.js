@@ -91,6 +91,13 @@ for (const n of [1024, 4096]) {
   for (let r = 0; r < reps; r++) acc += p.spectrumBatch(frames, opts)[255].peak.amplitude;
   const us = (now() - t0) / (reps * 256);
   out.cases.push({ n: n, op: 'spectrumBatch(256 frames, hann) per frame', gpu_dropin: { median_us: us, min_us: us, p95_us: us }, guard: acc });
+  // the same frames as Float32Arrays (audio): read where they lie through pdsp_spectrum_rows_host_f32in
+  const f32 = frames.map((f) => Float32Array.from(f));
+  for (let w = 0; w < 5; w++) p.spectrumBatch(f32, opts);
+  const t1 = now();
+  for (let r = 0; r < reps; r++) acc += p.spectrumBatch(f32, opts)[255].peak.amplitude;
+  const us32 = (now() - t1) / (reps * 256);
+  out.cases.push({ n: n, op: 'spectrumBatch(256 Float32Array frames, hann) per frame', gpu_dropin: { median_us: us32, min_us: us32, p95_us: us32 }, guard: acc });
 }
 // FFT.forwardBatch: the reference's batch idiom (bench/reallife/signals.ts:264-270, `for (...) fft.forward(input)`)
 // as one call, 256 rows, beside the same rows through 256 forward() calls and through the Node CPU path

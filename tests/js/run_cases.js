@@ -64,6 +64,16 @@ const results = cases.map((c) => {
             eq(rs[i].phase, plain[i].phase) && rs[i].peak.index === plain[i].peak.index &&
             rs[i].peak.amplitude === plain[i].peak.amplitude && rs[i].peak.phase === plain[i].peak.phase;
         }
+        // Float32Array frames (audio) are read where they lie too: results equal those of the same values as plain
+        // arrays (widening float -> double is exact); a run that mixes the two kinds falls back to flattening
+        const asF32 = c.frames.map((f) => Float32Array.from(f));
+        const r32 = p.spectrumBatch(asF32, c.options);
+        const widened = p.spectrumBatch(asF32.map((f) => Array.from(f)), c.options);
+        const mixedKinds = p.spectrumBatch(asF32.map((f, i) => (i % 2 ? Float64Array.from(f) : f)), c.options);
+        for (let i = 0; same && i < r32.length; i++) {
+          same = eq(r32[i].amplitude, widened[i].amplitude) && eq(r32[i].phase, widened[i].phase) &&
+            r32[i].peak.index === widened[i].peak.index && eq(mixedKinds[i].amplitude, widened[i].amplitude);
+        }
         return { same: same, count: rs.length };
       }
       case 'spectrumBatchBig': {
@@ -87,6 +97,12 @@ const results = cases.map((c) => {
           const one = p.spectrum(frames[i], c.options);
           same = eq(rs[i].amplitude, one.amplitude) && eq(rs[i].phase, one.phase) && rs[i].peak.index === one.peak.index &&
             eq(plain[i].amplitude, one.amplitude) && eq(plain[i].phase, one.phase) && plain[i].peak.index === one.peak.index;
+        }
+        const f32frames = frames.map((f) => Float32Array.from(f));
+        const r32 = p.spectrumBatch(f32frames, c.options);
+        for (const i of [0, 1, c.count >> 1, c.count - 1]) {
+          const one = p.spectrum(f32frames[i], c.options);
+          same = same && eq(r32[i].amplitude, one.amplitude) && eq(r32[i].phase, one.phase) && r32[i].peak.index === one.peak.index;
         }
         return { same: same, count: rs.length, lastPeak: rs[c.count - 1].peak.index };
       }

@@ -201,3 +201,26 @@ def test_transform_rows_variant_equals_contiguous_planes(capi, precision, n, bat
         assert capi.lib.pdsp_fft_transform_rows_host_f64(plan, batch, n, rp, None, capi.dptr(ore), capi.dptr(oim), 1) == capi.ERR_BAD_ARG
     finally:
         capi.lib.pdsp_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("n,length,batch", [(1024, 1024, 1501), (4096, 3000, 40), (8, 8, 3)])
+def test_f32_input_rows_equal_the_widened_f64_frames(capi, precision, n, length, batch):
+    """pdsp_spectrum_rows_host_f32in (Float32Array audio frames, one pointer per frame) against
+    pdsp_spectrum_batch_host_f64 on the same samples widened to f64 (exact): identical results, chunked or not."""
+    capi.lib.pdsp_set_host_precision(precision)
+    rng = np.random.default_rng(21 + n)
+    frames = [rng.standard_normal(length).astype(np.float32) for _ in range(batch)]
+    x = np.stack(frames).astype(np.float64)
+    fp = C.POINTER(C.c_float)
+    rows = (fp * batch)(*[f.ctypes.data_as(fp) for f in frames])
+    bins = n // 2 + 1
+    for threads in (1, 4):
+        want = _spectrum_batch(capi, x, n, 2, 0, threads)
+        freq, amp, ph = np.full(bins, np.nan), np.full((batch, bins), np.nan), np.full((batch, bins), np.nan)
+        peaks = (capi.Peak * batch)()
+        capi.check(capi.lib.pdsp_spectrum_rows_host_f32in(rows, batch, length, 48000.0, n, 2, 0, capi.dptr(freq), capi.dptr(amp),
+                                                          capi.dptr(ph), peaks, None))
+        pk = np.array([(p.index, p.frequency, p.amplitude, p.phase) for p in peaks])
+        for a, b in zip(want, (freq, amp, ph, pk)):
+            assert np.array_equal(a, b)

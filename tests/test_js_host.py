@@ -252,7 +252,10 @@ def test_napi_addon_argument_handling_under_address_sanitizer(tmp_path):
                  "spectrum bad size", "spectrumRows not an array", "spectrumRows range past the end",
                  "spectrumRows negative start", "spectrumRows ragged frame", "spectrumRows plain-array frame",
                  "spectrumRows hole", "spectrumRows short out", "spectrumRows bad size", "spectrumRows bad rate",
-                 "transformBatch wrong plan", "transformRows wrong plan", "transformRows not an array"):
+                 "transformBatch wrong plan", "transformRows wrong plan", "transformRows not an array",
+                 "spectrumRows mixed kinds", "spectrumRows Int32Array frame"):
         assert log[name][0] == "throws", (name, log[name])
+    # well-formed Float32Array frames: computes where a GPU is present (zeros in, amplitude 0 out), else the device error
+    assert log["spectrumRows f32 frames"] == ("ok", "0") or log["spectrumRows f32 frames"][0] == "throws"
     assert log["spectrumRows bad size"] == ("throws", "FFT size must be power of two, got 12")
     assert log["spectrumRows bad rate"] == ("throws", "Sample rate must be positive, got 0")
