@@ -18,10 +18,10 @@ from .fourier import (  # noqa: F401
     magnitude,
     phase,
 )
-from .spectrum import SpectrumPeak, SpectrumResult, spectrum  # noqa: F401
+from .spectrum import SpectrumPeak, SpectrumResult, spectrum, spectrumBatch  # noqa: F401
 
 __all__ = [
     "ComplexArray", "Radix2Fft", "createComplexArray", "isPowerOfTwo", "nextPowerOfTwo",
     "FFT", "applyWindow", "binFrequencies", "createWindow", "fftShift", "fftShiftComplex",
-    "magnitude", "phase", "spectrum", "SpectrumPeak", "SpectrumResult", "PdspError",
+    "magnitude", "phase", "spectrum", "spectrumBatch", "SpectrumPeak", "SpectrumResult", "PdspError",
 ]

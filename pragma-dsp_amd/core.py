@@ -121,6 +121,40 @@ class Radix2Fft:
         re, im = _complex_planes(input)
         return self._transform(re, im, out, True)
 
+    # -- extensions (as in the JS host, js/core.js): many rows in one call ----------
+    def forwardBatch(self, inputs) -> list:
+        """Element i equals forward(inputs[i]): the loop of the reference's batch idiom
+        (bench/reallife/signals.ts:264-270) as one device batch; the ComplexArrays of a batch are
+        views into one buffer per plane."""
+        return self._transform_batch(inputs, False, False)
+
+    def forwardComplexBatch(self, inputs) -> list:
+        return self._transform_batch(inputs, True, False)
+
+    def inverseBatch(self, inputs) -> list:
+        return self._transform_batch(inputs, True, True)
+
+    def _transform_batch(self, inputs, complex_rows: bool, inverse: bool) -> list:
+        n, batch = self.size, len(inputs)
+        re_rows, im_rows = [], []
+        for item in inputs:  # the length checks of fft.ts:95-104, per row
+            r, i = _complex_planes(item) if complex_rows else (item, None)
+            if len(r) != n:
+                raise PdspError(_capi.ERR_INPUT_LENGTH, f"FFT input length {len(r)} != size {n}")
+            if i is not None and len(i) != n:
+                raise PdspError(_capi.ERR_INPUT_LENGTH, f"FFT input length {len(i)} != size {n}")
+            re_rows.append(np.ascontiguousarray(as_f64(r)))
+            if complex_rows:
+                im_rows.append(np.ascontiguousarray(as_f64(i)))
+        ore = np.empty((batch, n), dtype=np.float64)
+        oim = np.empty((batch, n), dtype=np.float64)
+        if batch:
+            dp = C.POINTER(C.c_double)
+            rp = (dp * batch)(*[dptr(r) for r in re_rows])  # rows are read where they lie
+            ip = (dp * batch)(*[dptr(r) for r in im_rows]) if complex_rows else None
+            check(lib.pdsp_fft_transform_rows_host_f64(self._h, batch, n, rp, ip, dptr(ore), dptr(oim), int(bool(inverse))))
+        return [ComplexArray(ore[b], oim[b]) for b in range(batch)]
+
     # -- fft.ts:89-151 -----------------------------------------------------------
     def _transform(self, input_real, input_imag, out, inverse: bool) -> ComplexArray:
         if len(input_real) != self.size:

@@ -62,6 +62,16 @@ class FFT:
     def createComplexArray(self, fill: float = 0) -> ComplexArray:
         return createComplexArray(self.size, fill)
 
+    # extensions (see Radix2Fft): many rows in one device batch
+    def forwardBatch(self, inputs) -> list:
+        return self._kernel.forwardBatch(inputs)
+
+    def forwardComplexBatch(self, inputs) -> list:
+        return self._kernel.forwardComplexBatch(inputs)
+
+    def inverseBatch(self, inputs) -> list:
+        return self._kernel.inverseBatch(inputs)
+
 
 def _polar(input, out, fn):
     re, im = _complex_planes(input)
