@@ -920,7 +920,8 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                 out["parity"] = parity_vs_oracle("spectrum", (re[sel].cpu().numpy(),),
                                                  (amp[sel].cpu().numpy().astype(np.float64),), n, "hann")
         if world == 1 and args.workload == "fft4096" and not args.no_also:
-            out["also"] = {"spectrum16k": also_spectrum16k(args, dev, rank),
+            out["also"] = {"placement": also_placement(args, dev, plan, re, im, ore, oim),
+                           "spectrum16k": also_spectrum16k(args, dev, rank),
                            "fft4096_f64": also_fft4096_f64(args, dev, rank, re, im),
                            "real4096": also_real4096(args, dev, plan, re, ore, oim)}
             try:  # configs[1]: one N = 1024 frame, latency (a reported extra: never fatal to the headline)
@@ -1224,6 +1225,45 @@ def also_real4096(args, dev, plan, re, ore, oim):
         res["parity"] = parity_vs_oracle("real", (re[sel].cpu().numpy(), None),
                                          (ore[sel].cpu().numpy().astype(np.float64), oim[sel].cpu().numpy().astype(np.float64)), n)
     return res
+
+
+def also_placement(args, dev, plan, re, im, ore, oim, sets: int = 5):
+    """How much of the headline's rate on THIS card and in THIS process is the placement of its planes (DESIGN section 5,
+    "What the spread of configs[2] is made of"): the same launch, the same inputs, on `sets` more output-plane pairs
+    allocated now and kept alive together -- each pair's rate repeats to ~0.4 %, pairs differ by up to 8-14 %.  Index 0
+    is the pair the timed region wrote (`value` is never taken from another pair).  Reported, not used."""
+    n, batch = plan.size, re.shape[0]
+    nbytes = 16 * batch * n
+    pairs = [(ore, oim)]
+    try:
+        for _ in range(sets):
+            pairs.append((torch.empty_like(ore), torch.empty_like(oim)))
+    except RuntimeError as exc:  # not enough free HBM: report what there is
+        if len(pairs) == 1:
+            return {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    rates = []
+    for _ in range(20):
+        plan.forward(re, im, out=pairs[0])
+    torch.cuda.synchronize(dev)
+    for a, b in pairs:
+        for _ in range(4):
+            plan.forward(re, im, out=(a, b))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            plan.forward(re, im, out=(a, b))
+        e1.record()
+        torch.cuda.synchronize(dev)
+        rates.append(nbytes / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9)
+    plan.forward(re, im, out=(ore, oim))  # the timed region's planes hold the transform again
+    torch.cuda.synchronize(dev)
+    del pairs
+    torch.cuda.empty_cache()
+    return {"config": {"workload": f"N={n} batch={batch} forwardComplex fp32, the timed inputs onto {len(rates)} output-plane pairs "
+                                   "(index 0 = the timed region's own)"},
+            "GBps_by_output_pair": rates, "frac_by_output_pair": [r / HBM_PEAK_GBPS for r in rates],
+            "spread_pct": 100.0 * (max(rates) / min(rates) - 1.0),
+            "note": "placement of the planes in HBM, not code: DESIGN section 5; `value` uses pair 0 only"}
 
 
 def also_fft4096_f64(args, dev, rank: int, re32, im32):
