@@ -224,3 +224,37 @@ def test_f32_input_rows_equal_the_widened_f64_frames(capi, precision, n, length,
         pk = np.array([(p.index, p.frequency, p.amplitude, p.phase) for p in peaks])
         for a, b in zip(want, (freq, amp, ph, pk)):
             assert np.array_equal(a, b)
+
+
+def test_two_threads_share_one_plan_on_the_chunked_path(capi):
+    """Two host threads in pdsp_fft_transform_host_f64 on the SAME plan, both calls large enough to be chunked: the
+    plan's mutex serialises them (its staging slots and streams belong to one call at a time); both get their rows."""
+    capi.lib.pdsp_set_host_precision(64)
+    n, batch = 2048, 1100
+    rng = np.random.default_rng(5)
+    data = [(rng.standard_normal((batch, n)), rng.standard_normal((batch, n))) for _ in range(2)]
+    plan = C.c_void_p()
+    capi.check(capi.lib.pdsp_plan_create(n, -1, C.byref(plan)))
+    try:
+        want = [_transform(capi, plan, re, im, 0, 1) for re, im in data]
+        os.environ["PDSP_HOST_THREADS"] = "3"
+        got, errs = [None, None], []
+
+        def run(i):
+            try:
+                for _ in range(3):
+                    ore, oim = np.full_like(data[i][0], np.nan), np.full_like(data[i][0], np.nan)
+                    capi.check(capi.lib.pdsp_fft_transform_host_f64(plan, batch, n, capi.dptr(data[i][0]), capi.dptr(data[i][1]),
+                                                                    capi.dptr(ore), capi.dptr(oim), 0))
+                    got[i] = (ore, oim)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        for w, g in zip(want, got):
+            assert np.array_equal(w[0], g[0]) and np.array_equal(w[1], g[1])
+    finally:
+        capi.lib.pdsp_plan_destroy(plan)
