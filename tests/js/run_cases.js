@@ -76,6 +76,22 @@ const results = cases.map((c) => {
         }
         return { same: same, count: rs.length };
       }
+      case 'spectrumBatchOverlap': {
+        // a short-time transform the JS way: frames are OVERLAPPING subarray views of one signal (hop = n / 4); the
+        // addon reads each view where it lies -- no copies -- and every result equals spectrum(view)
+        const sig = new Float64Array(c.n * 6);
+        for (let i = 0; i < sig.length; i++) sig[i] = Math.sin(2 * Math.PI * (40 + i / 997) * i / c.n) + 0.01 * ((i * 7919) % 13);
+        const hop = c.n / 4, frames = [];
+        for (let o = 0; o + c.n <= sig.length; o += hop) frames.push(sig.subarray(o, o + c.n));
+        const rs = p.spectrumBatch(frames, c.options);
+        const eq = (a, b) => a.length === b.length && a.every((v, i) => Object.is(v, b[i]) || v === b[i]);
+        let same = rs.length === frames.length;
+        for (let i = 0; same && i < rs.length; i++) {
+          const one = p.spectrum(frames[i], c.options);
+          same = eq(rs[i].amplitude, one.amplitude) && eq(rs[i].phase, one.phase) && rs[i].peak.index === one.peak.index;
+        }
+        return { same: same, count: rs.length };
+      }
       case 'spectrumBatchBig': {
         // enough frames for the library to cut the call into chunks on several workers: every sampled result must
         // still equal the one-frame spectrum() exactly, from Float64Array frames and from plain arrays

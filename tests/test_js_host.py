@@ -103,7 +103,9 @@ def test_js_dropin_parity(tmp_path, oracle_mod, reallife, manifest):
     # FFT.forwardBatch / forwardComplexBatch / inverseBatch (the reference's batch loop, bench/reallife/signals.ts:264-270,
     # as one device batch): a small call and one large enough for the library's chunked path (300 rows of 8192)
     typed_cases += [{"op": "transformBatch", "n": 1024, "count": 9}, {"op": "transformBatch", "n": 8192, "count": 300}]
+    typed_cases.append({"op": "spectrumBatchOverlap", "n": 1024, "options": {"sampleRate": 48000, "window": "hann"}})
     tres = run_cases(typed_cases, tmp_path)
+    assert tres[6] == {"same": True, "count": 21}   # (6 n - n) / (n / 4) + 1 overlapping views
     for tb in tres[4:6]:
         assert tb["same"] is True and tb["roundTrip"] < 1e-12 and tb["empty"] == 0
         assert tb["threw"] == "FFT input length 3 != size " + str(1024 if tb["count"] == 9 else 8192)
