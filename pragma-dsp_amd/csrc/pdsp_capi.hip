@@ -480,7 +480,8 @@ int require_device() {
 // slot and one stream and draw chunks from a shared counter: fill the slot, H2D, the same kernels the one-shot path
 // launches, D2H, wait for the stream, unstage (+ findPeak).  Inside a worker the steps stay in order; across workers
 // staging, both PCIe directions and the kernels overlap.  Row b of the result is the one-shot result of row b bit
-// for bit (the kernels work row by row and the variant does not depend on the row count).
+// for bit (the kernels work row by row and the variant does not depend on the row count).  A worker keeps one
+// chunk on the card while it fills the next (two slots and streams per worker).
 // PDSP_HOST_THREADS sets K (1 = the one-shot sequence; default: half the cores this process may run on, 2 ... 6).
 constexpr size_t kChunkInBytes = (size_t)2 << 20;
 constexpr size_t kChunkedMinBytes = (size_t)8 << 20;
@@ -512,13 +513,17 @@ struct ChunkJob {
   hipStream_t stream = nullptr;
 };
 
-// body(job) -> pdsp status, error text in the running thread's g_err.  Caller holds plan->mu and has staged
-// `workers` slots (ensure_stage).  The first failure stops the hand-out of chunks and is what the call returns.
-template <class Body>
-int run_chunked(pdsp_plan *plan, long long rows, long long rows_per_chunk, int workers, Body body) {
+// submit(job) fills the job's slot and enqueues its copies and kernels on the job's stream without waiting;
+// finish(job) is called after that stream has drained and unstages the results.  Both return a pdsp status (error
+// text in the running thread's g_err).  Each worker owns TWO slots and streams and keeps one chunk on the card while
+// it fills the next (slot = 2 * worker + parity), so the caller has staged 2 * `workers` slots (ensure_stage) and
+// holds plan->mu.  The first failure stops the hand-out of chunks and is what the call returns.
+constexpr int kSlotsPerWorker = 2;
+template <class Submit, class Finish>
+int run_chunked(pdsp_plan *plan, long long rows, long long rows_per_chunk, int workers, Submit submit, Finish finish) {
   const long long nchunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
   if (workers > nchunks) workers = (int)nchunks;
-  while ((long long)plan->slot_streams.size() < workers) {
+  while ((long long)plan->slot_streams.size() < (long long)kSlotsPerWorker * workers) {
     hipStream_t st = nullptr;
     PDSP_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     plan->slot_streams.push_back(st);
@@ -535,26 +540,47 @@ int run_chunked(pdsp_plan *plan, long long rows, long long rows_per_chunk, int w
     }
   };
   auto worker = [&](int w) {
-    const hipStream_t st = plan->slot_streams[(size_t)w];
     const hipError_t e = hipSetDevice(plan->device);  // helpers start on device 0
     if (e != hipSuccess) {
       report(fail(PDSP_ERR_DEVICE, "HIP error %d (%s) at hipSetDevice", (int)e, hipGetErrorString(e)));
       return;
     }
+    ChunkJob in_flight;  // the chunk this worker has on the card (count == 0: none)
+    auto complete = [&]() -> int {  // wait for the chunk in flight and unstage it
+      if (in_flight.count == 0) return PDSP_OK;
+      const hipError_t se = hipStreamSynchronize(in_flight.stream);
+      int rc = PDSP_OK;
+      if (se != hipSuccess) rc = fail(PDSP_ERR_DEVICE, "HIP error %d (%s) at hipStreamSynchronize", (int)se, hipGetErrorString(se));
+      else rc = finish(in_flight);
+      in_flight.count = 0;
+      return rc;
+    };
+    int parity = 0;
     while (status.load() == PDSP_OK) {
       const long long c = next.fetch_add(1);
       if (c >= nchunks) break;
       ChunkJob job;
       job.first = c * rows_per_chunk;
       job.count = rows - job.first < rows_per_chunk ? rows - job.first : rows_per_chunk;
-      job.slot = w;
-      job.stream = st;
-      if (const int rc = body(job)) {
+      job.slot = kSlotsPerWorker * w + parity;
+      job.stream = plan->slot_streams[(size_t)job.slot];
+      if (const int rc = submit(job)) {  // fills the OTHER slot while in_flight's chunk is on the card
         report(rc);
         break;
       }
+      if (const int rc = complete()) {
+        report(rc);
+        in_flight = job;  // drained below
+        break;
+      }
+      in_flight = job;
+      parity ^= 1;
     }
-    (void)hipStreamSynchronize(st);  // nothing of this call stays in flight on the slot, on any exit
+    if (status.load() == PDSP_OK) {
+      if (const int rc = complete()) report(rc);
+    }
+    // nothing of this call stays in flight on the worker's slots, on any exit
+    for (int q = 0; q < kSlotsPerWorker; ++q) (void)hipStreamSynchronize(plan->slot_streams[(size_t)(kSlotsPerWorker * w + q)]);
   };
   std::vector<std::thread> helpers;
   helpers.reserve((size_t)workers);
@@ -611,7 +637,9 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
     // many rows: chunks on several workers (run_chunked); planes that overlap each other in host memory keep the
     // one-shot sequence, which has read every input before it writes any output
     const size_t row_bytes = n * sizeof(T), out_bytes = cnt * sizeof(double), in_row_bytes = n * sizeof(double);
-    const long long per_chunk = (long long)(kChunkInBytes / ((has_im ? 2 : 1) * row_bytes));
+    // (two planes' worth whether or not there is an imaginary input: the slot -- re | im | out re | out im -- stays
+    // at 2 x kChunkInBytes, so 2 slots x 6 workers fit the staging a plan keeps between calls)
+    const long long per_chunk = (long long)(kChunkInBytes / (2 * row_bytes));
     const int workers = host_workers(tables<T>(plan).log2n1 > 0);
     bool overlap = false;
     if (re_rows || im_rows) {
@@ -627,22 +655,28 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
     if (workers >= 2 && per_chunk >= 1 && batch >= 2 * per_chunk && 4 * cnt * sizeof(T) >= kChunkedMinBytes && !overlap) {
       const size_t slot = 4 * (size_t)per_chunk * n;  // elements: re | im | out re | out im
       const int k = (long long)workers < (batch + per_chunk - 1) / per_chunk ? workers : (int)((batch + per_chunk - 1) / per_chunk);
-      if (int rc = ensure_stage(plan, (size_t)k * slot * sizeof(T))) return rc;
-      return run_chunked(plan, batch, per_chunk, k, [&](const ChunkJob &job) -> int {
-        const size_t c = (size_t)job.count * n, off = (size_t)job.first * n;
-        T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
-        stage_in(h, h + c, job.first, job.count);
-        PDSP_HIP_TRY(hipMemcpyAsync(d, h, (has_im ? 2 : 1) * c * sizeof(T), hipMemcpyHostToDevice, job.stream));
-        int rc;
-        if (inverse) rc = run_complex<T>(plan, job.count, d + c, d, d + 3 * c, d + 2 * c, T(1) / (T)plan->n, job.stream);
-        else rc = run_complex<T>(plan, job.count, d, has_im ? d + c : nullptr, d + 2 * c, d + 3 * c, T(1), job.stream);
-        if (rc) return rc;
-        PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * c, d + 2 * c, 2 * c * sizeof(T), hipMemcpyDeviceToHost, job.stream));
-        PDSP_HIP_TRY(hipStreamSynchronize(job.stream));
-        stage_to_rows<T>(re_out + off, h + 2 * c, c);
-        stage_to_rows<T>(im_out + off, h + 3 * c, c);
-        return PDSP_OK;
-      });
+      if (int rc = ensure_stage(plan, (size_t)kSlotsPerWorker * k * slot * sizeof(T))) return rc;
+      return run_chunked(
+          plan, batch, per_chunk, k,
+          [&](const ChunkJob &job) -> int {  // submit
+            const size_t c = (size_t)job.count * n;
+            T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
+            stage_in(h, h + c, job.first, job.count);
+            PDSP_HIP_TRY(hipMemcpyAsync(d, h, (has_im ? 2 : 1) * c * sizeof(T), hipMemcpyHostToDevice, job.stream));
+            int rc;
+            if (inverse) rc = run_complex<T>(plan, job.count, d + c, d, d + 3 * c, d + 2 * c, T(1) / (T)plan->n, job.stream);
+            else rc = run_complex<T>(plan, job.count, d, has_im ? d + c : nullptr, d + 2 * c, d + 3 * c, T(1), job.stream);
+            if (rc) return rc;
+            PDSP_HIP_TRY(hipMemcpyAsync(h + 2 * c, d + 2 * c, 2 * c * sizeof(T), hipMemcpyDeviceToHost, job.stream));
+            return PDSP_OK;
+          },
+          [&](const ChunkJob &job) -> int {  // finish
+            const size_t c = (size_t)job.count * n, off = (size_t)job.first * n;
+            const T *h = (const T *)plan->h_stage + (size_t)job.slot * slot;
+            stage_to_rows<T>(re_out + off, h + 2 * c, c);
+            stage_to_rows<T>(im_out + off, h + 3 * c, c);
+            return PDSP_OK;
+          });
     }
   }
   if (int rc = ensure_stage(plan, 4 * cnt * sizeof(T))) return rc;
@@ -774,27 +808,33 @@ int spectrum_host_t(pdsp_plan *plan, const FrameSource &in, int window, int side
       const size_t slot = (ph_off + (size_t)per_chunk * (size_t)bins + 3) & ~(size_t)3;
       const long long nchunks = (batch + per_chunk - 1) / per_chunk;
       const int k = (long long)workers < nchunks ? workers : (int)nchunks;
-      if (int rc = ensure_stage(plan, (size_t)k * slot * sizeof(T))) return rc;
-      return run_chunked(plan, batch, per_chunk, k, [&](const ChunkJob &job) -> int {
-        T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
-        for (long long b = 0; b < job.count; ++b) {
-          T *dst = h + (size_t)b * (size_t)n;
-          in.stage<T>(dst, job.first + b, (size_t)used);
-          if (used < n) std::memset(dst + used, 0, (size_t)(n - used) * sizeof(T));
-        }
-        const size_t rows = (size_t)job.count * (size_t)bins;
-        PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)job.count * frame_bytes, hipMemcpyHostToDevice, job.stream));
-        if (int rc = spectrum_impl<T>(plan, job.count, d, n, n, d_window, sides, d + amp_off, d + ph_off, nullptr, nullptr,
-                                      1.0, job.stream))
-          return rc;
-        PDSP_HIP_TRY(hipMemcpyAsync(h + amp_off, d + amp_off, rows * sizeof(T), hipMemcpyDeviceToHost, job.stream));
-        PDSP_HIP_TRY(hipMemcpyAsync(h + ph_off, d + ph_off, rows * sizeof(T), hipMemcpyDeviceToHost, job.stream));
-        PDSP_HIP_TRY(hipStreamSynchronize(job.stream));
-        stage_to_rows<T>(amp_out + (size_t)job.first * (size_t)bins, h + amp_off, rows);
-        stage_to_rows<T>(phase_out + (size_t)job.first * (size_t)bins, h + ph_off, rows);
-        if (peak_out) host_peaks(freq, amp_out, phase_out, bins, job.first, job.count, peak_out);
-        return PDSP_OK;
-      });
+      if (int rc = ensure_stage(plan, (size_t)kSlotsPerWorker * k * slot * sizeof(T))) return rc;
+      return run_chunked(
+          plan, batch, per_chunk, k,
+          [&](const ChunkJob &job) -> int {  // submit
+            T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
+            for (long long b = 0; b < job.count; ++b) {
+              T *dst = h + (size_t)b * (size_t)n;
+              in.stage<T>(dst, job.first + b, (size_t)used);
+              if (used < n) std::memset(dst + used, 0, (size_t)(n - used) * sizeof(T));
+            }
+            const size_t rows = (size_t)job.count * (size_t)bins;
+            PDSP_HIP_TRY(hipMemcpyAsync(d, h, (size_t)job.count * frame_bytes, hipMemcpyHostToDevice, job.stream));
+            if (int rc = spectrum_impl<T>(plan, job.count, d, n, n, d_window, sides, d + amp_off, d + ph_off, nullptr,
+                                          nullptr, 1.0, job.stream))
+              return rc;
+            PDSP_HIP_TRY(hipMemcpyAsync(h + amp_off, d + amp_off, rows * sizeof(T), hipMemcpyDeviceToHost, job.stream));
+            PDSP_HIP_TRY(hipMemcpyAsync(h + ph_off, d + ph_off, rows * sizeof(T), hipMemcpyDeviceToHost, job.stream));
+            return PDSP_OK;
+          },
+          [&](const ChunkJob &job) -> int {  // finish
+            const T *h = (const T *)plan->h_stage + (size_t)job.slot * slot;
+            const size_t rows = (size_t)job.count * (size_t)bins;
+            stage_to_rows<T>(amp_out + (size_t)job.first * (size_t)bins, h + amp_off, rows);
+            stage_to_rows<T>(phase_out + (size_t)job.first * (size_t)bins, h + ph_off, rows);
+            if (peak_out) host_peaks(freq, amp_out, phase_out, bins, job.first, job.count, peak_out);
+            return PDSP_OK;
+          });
     }
   }
   // staging: [batch frames of n][batch rows of amp][batch rows of phase]; rows start 16-byte aligned
