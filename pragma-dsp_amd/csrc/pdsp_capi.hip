@@ -600,15 +600,39 @@ int run_chunked(pdsp_plan *plan, long long rows, long long rows_per_chunk, int w
   return PDSP_OK;
 }
 
+// f64 staging copies (the caller's rows <-> the pinned slots) with non-temporal 16-byte stores: the destination
+// lines are not read again by this core, so the read-for-ownership a plain store pays is pure host-memory traffic --
+// and host memory traffic (48 bytes per sample between the staging copies and the DMA engines) is what bounds the
+// chunked calls.  Measured, 6 workers: transforms +11 ... +15 %, spectrum at N = 4096 +11 ... +21 %, at N = 16384 +-0.
+// The closing sfence orders the stores before the copy command that reads the slot.  PDSP_NT_COPY=0: plain memcpy.
+inline bool nt_copy() {
+  static const bool on = [] { const char *e = getenv("PDSP_NT_COPY"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+inline void copy_f64(double *dst, const double *src, size_t count) {
+#if defined(__x86_64__)
+  typedef double v2d __attribute__((vector_size(16), aligned(16)));
+  typedef double v2du __attribute__((vector_size(16), aligned(8)));
+  if (nt_copy() && count >= 64 && !((uintptr_t)dst & 7) && !((uintptr_t)src & 7)) {
+    size_t i = 0;
+    if ((uintptr_t)dst & 15) dst[i] = src[i], ++i;
+    for (; i + 2 <= count; i += 2) __builtin_nontemporal_store(*(const v2du *)(src + i), (v2d *)(dst + i));
+    for (; i < count; ++i) dst[i] = src[i];
+    __builtin_ia32_sfence();
+    return;
+  }
+#endif
+  std::memcpy(dst, src, count * sizeof(double));
+}
 template <typename T>
 inline void rows_to_stage(T *dst, const double *src, size_t count) {
-  if constexpr (sizeof(T) == sizeof(double)) std::memcpy(dst, src, count * sizeof(double));
+  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count);
   else
     for (size_t i = 0; i < count; ++i) dst[i] = (T)src[i];
 }
 template <typename T>
 inline void stage_to_rows(double *dst, const T *src, size_t count) {
-  if constexpr (sizeof(T) == sizeof(double)) std::memcpy(dst, src, count * sizeof(double));
+  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count);
   else
     for (size_t i = 0; i < count; ++i) dst[i] = (double)src[i];
 }
