@@ -609,11 +609,12 @@ inline bool nt_copy() {
   static const bool on = [] { const char *e = getenv("PDSP_NT_COPY"); return !(e && atoi(e) == 0); }();
   return on;
 }
-inline void copy_f64(double *dst, const double *src, size_t count) {
+// `nt`: the chunked paths only -- a one-frame call's few KiB are read by its caller next, and should stay in cache.
+inline void copy_f64(double *dst, const double *src, size_t count, bool nt) {
 #if defined(__x86_64__)
   typedef double v2d __attribute__((vector_size(16), aligned(16)));
   typedef double v2du __attribute__((vector_size(16), aligned(8)));
-  if (nt_copy() && count >= 64 && !((uintptr_t)dst & 7) && !((uintptr_t)src & 7)) {
+  if (nt && nt_copy() && count >= 64 && !((uintptr_t)dst & 7) && !((uintptr_t)src & 7)) {
     size_t i = 0;
     if ((uintptr_t)dst & 15) dst[i] = src[i], ++i;
     for (; i + 2 <= count; i += 2) __builtin_nontemporal_store(*(const v2du *)(src + i), (v2d *)(dst + i));
@@ -625,14 +626,14 @@ inline void copy_f64(double *dst, const double *src, size_t count) {
   std::memcpy(dst, src, count * sizeof(double));
 }
 template <typename T>
-inline void rows_to_stage(T *dst, const double *src, size_t count) {
-  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count);
+inline void rows_to_stage(T *dst, const double *src, size_t count, bool nt = false) {
+  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count, nt);
   else
     for (size_t i = 0; i < count; ++i) dst[i] = (T)src[i];
 }
 template <typename T>
-inline void stage_to_rows(double *dst, const T *src, size_t count) {
-  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count);
+inline void stage_to_rows(double *dst, const T *src, size_t count, bool nt = false) {
+  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count, nt);
   else
     for (size_t i = 0; i < count; ++i) dst[i] = (double)src[i];
 }
@@ -648,14 +649,14 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
   auto re_row = [&](long long r) { return re_rows ? re_rows[r] : re_in + (size_t)r * n; };
   auto im_row = [&](long long r) { return im_rows ? im_rows[r] : im_in + (size_t)r * n; };
   // rows [first, first + count) into staging planes of `count` rows each
-  auto stage_in = [&](T *h_re, T *h_im, long long first, long long count) {
-    if (!re_rows) rows_to_stage<T>(h_re, re_in + (size_t)first * n, (size_t)count * n);
+  auto stage_in = [&](T *h_re, T *h_im, long long first, long long count, bool nt) {
+    if (!re_rows) rows_to_stage<T>(h_re, re_in + (size_t)first * n, (size_t)count * n, nt);
     else
-      for (long long r = 0; r < count; ++r) rows_to_stage<T>(h_re + (size_t)r * n, re_rows[first + r], n);
+      for (long long r = 0; r < count; ++r) rows_to_stage<T>(h_re + (size_t)r * n, re_rows[first + r], n, nt);
     if (!has_im) return;
-    if (!im_rows) rows_to_stage<T>(h_im, im_in + (size_t)first * n, (size_t)count * n);
+    if (!im_rows) rows_to_stage<T>(h_im, im_in + (size_t)first * n, (size_t)count * n, nt);
     else
-      for (long long r = 0; r < count; ++r) rows_to_stage<T>(h_im + (size_t)r * n, im_rows[first + r], n);
+      for (long long r = 0; r < count; ++r) rows_to_stage<T>(h_im + (size_t)r * n, im_rows[first + r], n, nt);
   };
   {
     // many rows: chunks on several workers (run_chunked); planes that overlap each other in host memory keep the
@@ -685,7 +686,7 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
           [&](const ChunkJob &job) -> int {  // submit
             const size_t c = (size_t)job.count * n;
             T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
-            stage_in(h, h + c, job.first, job.count);
+            stage_in(h, h + c, job.first, job.count, true);
             PDSP_HIP_TRY(hipMemcpyAsync(d, h, (has_im ? 2 : 1) * c * sizeof(T), hipMemcpyHostToDevice, job.stream));
             int rc;
             if (inverse) rc = run_complex<T>(plan, job.count, d + c, d, d + 3 * c, d + 2 * c, T(1) / (T)plan->n, job.stream);
@@ -697,8 +698,8 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
           [&](const ChunkJob &job) -> int {  // finish
             const size_t c = (size_t)job.count * n, off = (size_t)job.first * n;
             const T *h = (const T *)plan->h_stage + (size_t)job.slot * slot;
-            stage_to_rows<T>(re_out + off, h + 2 * c, c);
-            stage_to_rows<T>(im_out + off, h + 3 * c, c);
+            stage_to_rows<T>(re_out + off, h + 2 * c, c, true);
+            stage_to_rows<T>(im_out + off, h + 3 * c, c, true);
             return PDSP_OK;
           });
     }
@@ -706,7 +707,7 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
   if (int rc = ensure_stage(plan, 4 * cnt * sizeof(T))) return rc;
   T *h_re = (T *)plan->h_stage, *h_im = h_re + cnt, *h_ore = h_im + cnt, *h_oim = h_ore + cnt;
   T *d_re = (T *)plan->d_stage, *d_im = d_re + cnt, *d_ore = d_im + cnt, *d_oim = d_ore + cnt;
-  stage_in(h_re, h_im, 0, batch);
+  stage_in(h_re, h_im, 0, batch, false);
   hipStream_t s = plan->stream;
   T *const z = zero_copy(4 * cnt * sizeof(T)) ? stage_device_view<T>(plan) : nullptr;
   if (z) {  // the kernels work on the pinned buffer itself
@@ -760,12 +761,12 @@ int polar_host_t(const double *re, const double *im, long long n_, double *out, 
 // `batch` frames of spectrum() (each `len` samples, contiguous) in precision T; plan->mu held by the
 // caller.  One frame (the drop-in spectrum()) and many (spectrumBatch) run the same kernel variant per
 // row, so row b of a batch equals the one-frame call on frame b bit for bit.
-// findPeak on the host over the f64 amplitudes of rows [first, first + count): exact strict-'>' and first-wins
+// findPeak on the host over `count` rows of f64 amplitudes: exact strict-'>' and first-wins
 // behaviour (spectrum.ts:74-105), peak.frequency from the call's one frequency axis.
-inline void host_peaks(const double *freq, const double *amp_out, const double *phase_out, long long bins,
-                       long long first, long long count, pdsp_peak *peak_out) {
-  for (long long b = first; b < first + count; ++b) {
-    const double *a = amp_out + (size_t)b * (size_t)bins, *p = phase_out + (size_t)b * (size_t)bins;
+inline void host_peaks(const double *freq, const double *amp_rows, const double *phase_rows, long long bins,
+                       long long count, pdsp_peak *peak_out) {
+  for (long long b = 0; b < count; ++b) {
+    const double *a = amp_rows + (size_t)b * (size_t)bins, *p = phase_rows + (size_t)b * (size_t)bins;
     const long long pk = pdsp_find_peak_f64(a, bins);
     peak_out[b].index = (int32_t)pk;
     peak_out[b].frequency = freq[pk];
@@ -788,14 +789,14 @@ struct FrameSource {
   }
   // the first `used` samples of frame b into staging of precision T
   template <typename T>
-  void stage(T *dst, long long b, size_t used) const {
+  void stage(T *dst, long long b, size_t used, bool nt = false) const {
     if (rows32) {
       const float *src = rows32[b];
       if constexpr (sizeof(T) == sizeof(float)) std::memcpy(dst, src, used * sizeof(float));
       else
         for (size_t i = 0; i < used; ++i) dst[i] = (T)src[i];
     } else {
-      rows_to_stage<T>(dst, (const double *)frame(b), used);
+      rows_to_stage<T>(dst, (const double *)frame(b), used, nt);
     }
   }
   bool overlaps(const void *out, size_t out_bytes, long long batch) const {
@@ -839,7 +840,7 @@ int spectrum_host_t(pdsp_plan *plan, const FrameSource &in, int window, int side
             T *h = (T *)plan->h_stage + (size_t)job.slot * slot, *d = (T *)plan->d_stage + (size_t)job.slot * slot;
             for (long long b = 0; b < job.count; ++b) {
               T *dst = h + (size_t)b * (size_t)n;
-              in.stage<T>(dst, job.first + b, (size_t)used);
+              in.stage<T>(dst, job.first + b, (size_t)used, true);
               if (used < n) std::memset(dst + used, 0, (size_t)(n - used) * sizeof(T));
             }
             const size_t rows = (size_t)job.count * (size_t)bins;
@@ -854,9 +855,16 @@ int spectrum_host_t(pdsp_plan *plan, const FrameSource &in, int window, int side
           [&](const ChunkJob &job) -> int {  // finish
             const T *h = (const T *)plan->h_stage + (size_t)job.slot * slot;
             const size_t rows = (size_t)job.count * (size_t)bins;
-            stage_to_rows<T>(amp_out + (size_t)job.first * (size_t)bins, h + amp_off, rows);
-            stage_to_rows<T>(phase_out + (size_t)job.first * (size_t)bins, h + ph_off, rows);
-            if (peak_out) host_peaks(freq, amp_out, phase_out, bins, job.first, job.count, peak_out);
+            // (host_peaks below reads the f64 rows from the slot, which is still in cache, not from the rows just streamed out)
+            stage_to_rows<T>(amp_out + (size_t)job.first * (size_t)bins, h + amp_off, rows, true);
+            stage_to_rows<T>(phase_out + (size_t)job.first * (size_t)bins, h + ph_off, rows, true);
+            if (peak_out) {
+              if constexpr (sizeof(T) == sizeof(double))
+                host_peaks(freq, (const double *)(h + amp_off), (const double *)(h + ph_off), bins, job.count, peak_out + job.first);
+              else
+                host_peaks(freq, amp_out + (size_t)job.first * (size_t)bins, phase_out + (size_t)job.first * (size_t)bins, bins,
+                           job.count, peak_out + job.first);
+            }
             return PDSP_OK;
           });
     }
@@ -886,7 +894,7 @@ int spectrum_host_t(pdsp_plan *plan, const FrameSource &in, int window, int side
   PDSP_HIP_TRY(hipStreamSynchronize(s));
   for (size_t i = 0; i < rows; ++i) amp_out[i] = (double)h[amp_off + i];
   for (size_t i = 0; i < rows; ++i) phase_out[i] = (double)h[ph_off + i];
-  if (peak_out) host_peaks(freq, amp_out, phase_out, bins, 0, batch, peak_out);
+  if (peak_out) host_peaks(freq, amp_out, phase_out, bins, batch, peak_out);
   return PDSP_OK;
 }
 
