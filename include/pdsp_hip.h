@@ -304,7 +304,7 @@ PDSP_API int pdsp_spectrum_host_f64(const double *samples, long long len, double
 /* The same on `batch` frames of `len` samples each (contiguous) in ONE call -- the map of the
  * reference's spectrumStream (src/effect/index.ts:190-194) batched onto the device.  freq_out holds
  * the one frequency axis (bins values); amp_out / phase_out batch*bins; peak_out batch records.
- * Row b equals pdsp_spectrum_host_f64 on frame b bit for bit.  Calls with 8 MiB or more of staging are cut into
+ * Row b equals pdsp_spectrum_host_f64 on frame b bit for bit.  Calls with 4 MiB or more of staging are cut into
  * chunks that several host threads (PDSP_HOST_THREADS; default half the cores, 2 ... 6; 1 = none) stage, copy and
  * launch concurrently on streams of their own -- the results do not depend on it. */
 PDSP_API int pdsp_spectrum_batch_host_f64(const double *frames, long long batch, long long len,

@@ -484,7 +484,17 @@ int require_device() {
 // chunk on the card while it fills the next (two slots and streams per worker).
 // PDSP_HOST_THREADS sets K (1 = the one-shot sequence; default: half the cores this process may run on, 2 ... 6).
 constexpr size_t kChunkInBytes = (size_t)2 << 20;
-constexpr size_t kChunkedMinBytes = (size_t)8 << 20;
+constexpr size_t kChunkedMinBytes = (size_t)4 << 20;
+// Input bytes per chunk for a call that stages `in_total` bytes of input on `workers` workers: 2 MiB, less for small
+// calls so that every worker still gets two chunks, not below 256 KiB.  (N = 1024 frames, us per call, one-shot /
+// fixed 2-MiB chunks / these: 256 frames 327 / - / 304, 512 frames 597 / 445 / 406, 1,024 frames 1,331 / 652 / 536,
+// 4,096 frames 14,663 / 1,405 / 1,527; 128 frames stay one-shot: 188 against 201.)
+size_t chunk_in_bytes(size_t in_total, int workers) {
+  size_t c = in_total / (size_t)(2 * (workers > 0 ? workers : 1));
+  if (c > kChunkInBytes) c = kChunkInBytes;
+  if (c < ((size_t)256 << 10)) c = (size_t)256 << 10;
+  return c;
+}
 
 // multipass: the size runs on the multi-pass paths, whose scratch planes come from the engine's stream-ordered pool --
 // planes freed on one stream are not reusable on another before a synchronisation, so many streams grow the pool
@@ -600,7 +610,7 @@ int run_chunked(pdsp_plan *plan, long long rows, long long rows_per_chunk, int w
   return PDSP_OK;
 }
 
-// f64 staging copies (the caller's rows <-> the pinned slots) with non-temporal 16-byte stores: the destination
+// f64 staging copies INTO the pinned slots (the caller's rows -> slot) with non-temporal 16-byte stores: the destination
 // lines are not read again by this core, so the read-for-ownership a plain store pays is pure host-memory traffic --
 // and host memory traffic (48 bytes per sample between the staging copies and the DMA engines) is what bounds the
 // chunked calls.  Measured, 6 workers: transforms +11 ... +15 %, spectrum at N = 4096 +11 ... +21 %, at N = 16384 +-0.
@@ -631,9 +641,11 @@ inline void rows_to_stage(T *dst, const double *src, size_t count, bool nt = fal
   else
     for (size_t i = 0; i < count; ++i) dst[i] = (T)src[i];
 }
+// (results go out with ordinary stores: a caller's fresh result arrays are in cache right after their first touch,
+// where a non-temporal store is the slower one; measured with reused arrays: no difference either way)
 template <typename T>
-inline void stage_to_rows(double *dst, const T *src, size_t count, bool nt = false) {
-  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count, nt);
+inline void stage_to_rows(double *dst, const T *src, size_t count) {
+  if constexpr (sizeof(T) == sizeof(double)) copy_f64(dst, src, count, false);
   else
     for (size_t i = 0; i < count; ++i) dst[i] = (double)src[i];
 }
@@ -664,8 +676,8 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
     const size_t row_bytes = n * sizeof(T), out_bytes = cnt * sizeof(double), in_row_bytes = n * sizeof(double);
     // (two planes' worth whether or not there is an imaginary input: the slot -- re | im | out re | out im -- stays
     // at 2 x kChunkInBytes, so 2 slots x 6 workers fit the staging a plan keeps between calls)
-    const long long per_chunk = (long long)(kChunkInBytes / (2 * row_bytes));
     const int workers = host_workers(tables<T>(plan).log2n1 > 0);
+    const long long per_chunk = (long long)(chunk_in_bytes(2 * cnt * sizeof(T), workers) / (2 * row_bytes));
     bool overlap = false;
     if (re_rows || im_rows) {
       for (long long r = 0; r < batch && !overlap; ++r)
@@ -698,8 +710,8 @@ int transform_host(pdsp_plan *plan, long long batch, const double *re_in, const 
           [&](const ChunkJob &job) -> int {  // finish
             const size_t c = (size_t)job.count * n, off = (size_t)job.first * n;
             const T *h = (const T *)plan->h_stage + (size_t)job.slot * slot;
-            stage_to_rows<T>(re_out + off, h + 2 * c, c, true);
-            stage_to_rows<T>(im_out + off, h + 3 * c, c, true);
+            stage_to_rows<T>(re_out + off, h + 2 * c, c);
+            stage_to_rows<T>(im_out + off, h + 3 * c, c);
             return PDSP_OK;
           });
     }
@@ -817,8 +829,8 @@ int spectrum_host_t(pdsp_plan *plan, const FrameSource &in, int window, int side
   {
     // many frames: chunks on several workers (run_chunked)
     const size_t frame_bytes = (size_t)n * sizeof(T);
-    const long long per_chunk = (long long)(kChunkInBytes / frame_bytes);
     const int workers = host_workers(tables<T>(plan).log2n1 > 0 && !tables<T>(plan).tw_half);  // packed-real frames: one pass
+    const long long per_chunk = (long long)(chunk_in_bytes((size_t)batch * frame_bytes, workers) / frame_bytes);
     const size_t out_b = (size_t)batch * (size_t)bins * sizeof(double);
     const bool overlap = len > 0 && (in.overlaps(amp_out, out_b, batch) || in.overlaps(phase_out, out_b, batch));
     if (workers >= 2 && per_chunk >= 1 && batch >= 2 * per_chunk && len > 0 &&
@@ -856,8 +868,8 @@ int spectrum_host_t(pdsp_plan *plan, const FrameSource &in, int window, int side
             const T *h = (const T *)plan->h_stage + (size_t)job.slot * slot;
             const size_t rows = (size_t)job.count * (size_t)bins;
             // (host_peaks below reads the f64 rows from the slot, which is still in cache, not from the rows just streamed out)
-            stage_to_rows<T>(amp_out + (size_t)job.first * (size_t)bins, h + amp_off, rows, true);
-            stage_to_rows<T>(phase_out + (size_t)job.first * (size_t)bins, h + ph_off, rows, true);
+            stage_to_rows<T>(amp_out + (size_t)job.first * (size_t)bins, h + amp_off, rows);
+            stage_to_rows<T>(phase_out + (size_t)job.first * (size_t)bins, h + ph_off, rows);
             if (peak_out) {
               if constexpr (sizeof(T) == sizeof(double))
                 host_peaks(freq, (const double *)(h + amp_off), (const double *)(h + ph_off), bins, job.count, peak_out + job.first);
