@@ -30,6 +30,18 @@ function timed(fn) {
   return stats(ts);
 }
 
+// batch forms: per-call times over `reps` calls -> median / min per element (a mean over 20 calls swung by 30 %)
+function timedCalls(fn, reps, per) {
+  for (let w = 0; w < 8; w++) fn();
+  const ts = new Array(reps);
+  for (let r = 0; r < reps; r++) {
+    const t0 = now();
+    fn();
+    ts[r] = (now() - t0) / per;
+  }
+  return stats(ts);
+}
+
 const out = { node: process.version, iterations: iters, cases: [] };
 let seed = 1337;
 const rnd = () => { seed ^= seed << 13; seed ^= seed >>> 17; seed ^= seed << 5; return (seed >>> 0) / 2147483648 - 1; };
@@ -84,20 +96,14 @@ for (const n of [1024, 4096]) {
     frames.push(f);
   }
   const opts = { sampleRate: 48000, fftSize: n, window: 'hann' };
-  for (let w = 0; w < 5; w++) p.spectrumBatch(frames, opts);
-  const reps = 20;
-  const t0 = now();
+  const reps = 80;
   let acc = 0;
-  for (let r = 0; r < reps; r++) acc += p.spectrumBatch(frames, opts)[255].peak.amplitude;
-  const us = (now() - t0) / (reps * 256);
-  out.cases.push({ n: n, op: 'spectrumBatch(256 frames, hann) per frame', gpu_dropin: { median_us: us, min_us: us, p95_us: us }, guard: acc });
+  const st = timedCalls(() => { acc += p.spectrumBatch(frames, opts)[255].peak.amplitude; }, reps, 256);
+  out.cases.push({ n: n, op: 'spectrumBatch(256 frames, hann) per frame', gpu_dropin: st, guard: acc });
   // the same frames as Float32Arrays (audio): read where they lie through pdsp_spectrum_rows_host_f32in
   const f32 = frames.map((f) => Float32Array.from(f));
-  for (let w = 0; w < 5; w++) p.spectrumBatch(f32, opts);
-  const t1 = now();
-  for (let r = 0; r < reps; r++) acc += p.spectrumBatch(f32, opts)[255].peak.amplitude;
-  const us32 = (now() - t1) / (reps * 256);
-  out.cases.push({ n: n, op: 'spectrumBatch(256 Float32Array frames, hann) per frame', gpu_dropin: { median_us: us32, min_us: us32, p95_us: us32 }, guard: acc });
+  const st32 = timedCalls(() => { acc += p.spectrumBatch(f32, opts)[255].peak.amplitude; }, reps, 256);
+  out.cases.push({ n: n, op: 'spectrumBatch(256 Float32Array frames, hann) per frame', gpu_dropin: st32, guard: acc });
 }
 // FFT.forwardBatch: the reference's batch idiom (bench/reallife/signals.ts:264-270, `for (...) fft.forward(input)`)
 // as one call, 256 rows, beside the same rows through 256 forward() calls and through the Node CPU path
@@ -110,17 +116,13 @@ for (const n of [1024, 4096]) {
     rows.push(f);
   }
   const fft = new p.fourier.FFT(n);
-  for (let w = 0; w < 5; w++) fft.forwardBatch(rows);
-  const reps = 20;
   let acc = 0;
-  let t0 = now();
-  for (let r = 0; r < reps; r++) acc += fft.forwardBatch(rows)[255].real[1];
-  const usBatch = (now() - t0) / (reps * 256);
+  const stb = timedCalls(() => { acc += fft.forwardBatch(rows)[255].real[1]; }, 80, 256);
   const outc = fft.createComplexArray();
-  t0 = now();
+  let t0 = now();
   for (let r = 0; r < 4; r++) for (let b = 0; b < 256; b++) acc += fft.forward(rows[b], outc).real[1];
   const usLoop = (now() - t0) / (4 * 256);
-  const row = { n: n, op: 'FFT.forwardBatch(256 rows) per row', gpu_dropin: { median_us: usBatch, min_us: usBatch, p95_us: usBatch },
+  const row = { n: n, op: 'FFT.forwardBatch(256 rows) per row', gpu_dropin: stb,
                 gpu_dropin_loop_of_forward: { median_us: usLoop }, guard: acc };
   if (cpu) {
     const plan = cpu.makePlan(n), oRe = new Float64Array(n), oIm = new Float64Array(n);
