@@ -784,36 +784,12 @@ fft_stockham_kernel(const LD ld, const ST st, const typename vec2<T>::type *__re
     twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
     load_order_fence();
   }
-#ifdef PDSP_PLANE_MAJOR
-  constexpr bool kPM = std::is_same<LD, LoadComplex<T>>::value && std::is_same<ST, StoreComplex<T>>::value && TR::ROWS == 1;
-#else
-  constexpr bool kPM = false;
-#endif
-  if constexpr (kPM) {
-#ifdef PDSP_PLANE_MAJOR
-    const size_t o = (size_t)row * (size_t)ld.n + (unsigned)tid;
-    static_for<E>([&](auto q) { x[q].x = ld_stream(ld.re + o + TP * q); });
-#if PDSP_PLANE_MAJOR == 2
-    load_order_fence();
-#endif
-    static_for<E>([&](auto q) { x[q].y = ld_stream(ld.im + o + TP * q); });
-#endif
-  } else {
-    static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
-  }
+  static_for<E>([&](auto q) { x[q] = ld(row, TP * q, tid); });
   if constexpr (kRegTw && !PDSP_TABLES_FIRST_C2C) twf.load(reinterpret_cast<const cx<T> *>(tw), tid);
   if constexpr (!kRegTw) twf.tw = reinterpret_cast<const cx<T> *>(tw);
   fft_passes<T, LOG2N, false>(x, lrow, twf, tid);
   if (live) {
-    if constexpr (kPM) {
-#ifdef PDSP_PLANE_MAJOR
-      const size_t o = (size_t)row * (size_t)st.n + (unsigned)tid;
-      static_for<E>([&](auto q) { st_stream(x[q].x * st.scale, st.re + o + TP * q); });
-      static_for<E>([&](auto q) { st_stream(x[q].y * st.scale, st.im + o + TP * q); });
-#endif
-    } else {
-      static_for<E>([&](auto q) { st(row, TP * q, tid, x[q]); });
-    }
+    static_for<E>([&](auto q) { st(row, TP * q, tid, x[q]); });
   }
 }
 
