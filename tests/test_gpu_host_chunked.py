@@ -258,3 +258,34 @@ def test_two_threads_share_one_plan_on_the_chunked_path(capi):
             assert np.array_equal(w[0], g[0]) and np.array_equal(w[1], g[1])
     finally:
         capi.lib.pdsp_plan_destroy(plan)
+
+
+def test_chunked_vs_one_shot_fuzz(capi):
+    """Random sizes, frame lengths, batch sizes, windows, sides, precisions and worker counts: the chunked batched
+    spectrum (contiguous, row-pointer and f32-row forms) always equals the one-shot sequence bit for bit."""
+    rng = np.random.default_rng(20260105)
+    dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    for case in range(24):
+        n = int(2 ** rng.integers(6, 14))
+        length = int(rng.choice([n, n, n - rng.integers(1, n // 2), n + rng.integers(1, n)]))
+        # enough frames for 1 ... 5 chunks of staging around the 4 MiB threshold
+        batch = int(max(2, rng.integers(1, 6) * (3 << 20) // (16 * n)) + rng.integers(0, 7))
+        window, sides, precision = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.choice([64, 32]))
+        threads = int(rng.integers(2, 7))
+        capi.lib.pdsp_set_host_precision(precision)
+        x32 = rng.standard_normal((batch, length)).astype(np.float32)
+        x = x32.astype(np.float64)
+        want = _spectrum_batch(capi, x, n, window, sides, 1)
+        got = _spectrum_batch(capi, x, n, window, sides, threads)
+        tag = f"case {case}: n={n} len={length} batch={batch} win={window} sides={sides} f{precision} threads={threads}"
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), tag
+        bins = n // 2 + 1 if sides == 0 else n
+        for rows, fn in (((dp * batch)(*[capi.dptr(r) for r in x]), capi.lib.pdsp_spectrum_rows_host_f64),
+                         ((fp * batch)(*[r.ctypes.data_as(fp) for r in x32]), capi.lib.pdsp_spectrum_rows_host_f32in)):
+            freq, amp, ph = np.full(bins, np.nan), np.full((batch, bins), np.nan), np.full((batch, bins), np.nan)
+            peaks = (capi.Peak * batch)()
+            capi.check(fn(rows, batch, length, 48000.0, n, window, sides, capi.dptr(freq), capi.dptr(amp), capi.dptr(ph), peaks, None))
+            pk = np.array([(p.index, p.frequency, p.amplitude, p.phase) for p in peaks])
+            for a, b in zip(want, (freq, amp, ph, pk)):
+                assert np.array_equal(a, b), tag + " (rows form)"
