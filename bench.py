@@ -54,6 +54,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured float4 copy
 
 
+PLANES_ARENA_NOTE = ("BatchedFft.alloc_planes: one allocation of 80 GiB + a plane, input planes back to back at its start, "
+                     "output planes 40 and 80 GiB in (each in a 32-GiB region of its own: DESIGN section 5)")
+
+
 def synth_batch(batch: int, n: int, device, seed: int = 1337, complex_noise: bool = True):
     """SURVEY 8(d) config 3 input: first half sines A*sin(2*pi*k*i/N + phi) with
     A~U[0.5,2], integer k~U{1..N/2-1}, phi~U[0,2pi), imag = 0; second half complex
@@ -545,6 +549,9 @@ def parse_args(argv):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--plain-planes", action="store_true",
+                    help="time the transform workloads on four plain allocations instead of the engine's plane layout "
+                         "(BatchedFft.alloc_planes)")
     ap.add_argument("--workload", default="fft4096", choices=["fft4096", "fft4096_f64", "real4096", "fft16k", "spectrum16k", "spectrum256", "peaks16k", "single1024", "stream", "hostbatch"])
     ap.add_argument("--batch", type=int, default=None, help="transforms per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None, help="spectrum256 only: another frame size (development sweeps)")
@@ -701,11 +708,21 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     stream = torch.cuda.current_stream(dev)
     parity_kind, amp = None, None
 
+    planes_note = "four plain allocations"
     if args.workload in ("fft4096", "fft16k", "fft4096_f64"):
         re, im = synth_batch(per_gpu, n, dev, seed=1337 + rank)
         if f64:
             re, im = re.double(), im.double()
-        ore, oim = torch.empty_like(re), torch.empty_like(im)
+        if args.plain_planes:
+            ore, oim = torch.empty_like(re), torch.empty_like(im)
+        else:  # the engine's plane layout (BatchedFft.alloc_planes): one allocation, outputs 40 / 80 GiB beyond the inputs
+            a_re, a_im, ore, oim = plan.alloc_planes(per_gpu)
+            a_re.copy_(re)
+            a_im.copy_(im)
+            re, im = a_re, a_im
+            del a_re, a_im
+            torch.cuda.empty_cache()
+            planes_note = PLANES_ARENA_NOTE if plan.arena is not None else "four plain allocations (no room for the arena layout)"
         launches_per_step = 1
         bytes_per_launch = (32 if f64 else 16) * per_gpu * n  # 8 B read + 8 B written per f32 sample
         parity_kind = "complex"
@@ -723,7 +740,15 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
     elif args.workload == "real4096":
         re, _ = synth_batch(per_gpu, n, dev, seed=1337 + rank, complex_noise=False)
         im = None
-        ore, oim = torch.empty_like(re), torch.empty_like(re)
+        if args.plain_planes:
+            ore, oim = torch.empty_like(re), torch.empty_like(re)
+        else:
+            a_re, _none, ore, oim = plan.alloc_planes(per_gpu, real_input=True)
+            a_re.copy_(re)
+            re = a_re
+            del a_re
+            torch.cuda.empty_cache()
+            planes_note = PLANES_ARENA_NOTE if plan.arena is not None else "four plain allocations (no room for the arena layout)"
         launches_per_step = 1
         bytes_per_launch = 12 * per_gpu * n
         parity_kind = "real"
@@ -867,6 +892,7 @@ def run_rank(args, world: int, rank: int, local: int) -> int:
                                     "spectrum256": f"N={n} batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude",
                                     "spectrum16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+one-sided amplitude (configs[3])",
                                     "peaks16k": f"N=16384 batch={per_gpu}/GPU fused hann+FFT+findPeak, peaks-only output"}[args.workload],
+                       "planes": planes_note,
                        "n": n, "batch_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "parallelism": f"batch-shard x{world}", "launches_per_step": launches_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -1255,13 +1281,34 @@ def also_placement(args, dev, plan, re, im, ore, oim, sets: int = 5):
         e1.record()
         torch.cuda.synchronize(dev)
         rates.append(nbytes / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9)
+    plain_all = None
+    if len(pairs) > 1:  # four plain allocations, inputs included: what a caller gets without the engine's layout
+        try:
+            pre, pim = torch.empty_like(re), torch.empty_like(im)
+            pre.copy_(re)
+            pim.copy_(im)
+            a, b = pairs[1]
+            for _ in range(4):
+                plan.forward(pre, pim, out=(a, b))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                plan.forward(pre, pim, out=(a, b))
+            e1.record()
+            torch.cuda.synchronize(dev)
+            plain_all = nbytes / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+            del pre, pim
+        except RuntimeError:
+            plain_all = None
     plan.forward(re, im, out=(ore, oim))  # the timed region's planes hold the transform again
     torch.cuda.synchronize(dev)
     del pairs
     torch.cuda.empty_cache()
     return {"config": {"workload": f"N={n} batch={batch} forwardComplex fp32, the timed inputs onto {len(rates)} output-plane pairs "
-                                   "(index 0 = the timed region's own)"},
+                                   "(index 0 = the timed region's own; the others are plain allocations made now)"},
             "GBps_by_output_pair": rates, "frac_by_output_pair": [r / HBM_PEAK_GBPS for r in rates],
+            "GBps_four_plain_allocations": plain_all,
+            "frac_four_plain_allocations": plain_all / HBM_PEAK_GBPS if plain_all else None,
             "spread_pct": 100.0 * (max(rates) / min(rates) - 1.0),
             "note": "placement of the planes in HBM, not code: DESIGN section 5; `value` uses pair 0 only"}
 
@@ -1275,8 +1322,13 @@ def also_fft4096_f64(args, dev, rank: int, re32, im32):
     batch = re32.shape[0]
     torch.cuda.empty_cache()
     plan = BatchedFft(n, dev, dtype=torch.float64)
-    re, im = re32.double(), im32.double()
-    ore, oim = torch.empty_like(re), torch.empty_like(im)
+    if args.plain_planes:
+        re, im = re32.double(), im32.double()
+        ore, oim = torch.empty_like(re), torch.empty_like(im)
+    else:  # the engine's plane layout, as in the timed region (4-GiB planes: inputs 0 / 4, outputs 40 / 80 GiB)
+        re, im, ore, oim = plan.alloc_planes(batch)
+        re.copy_(re32)
+        im.copy_(im32)
     stream = torch.cuda.current_stream(dev)
     t_ramp = time.perf_counter()
     plan.forward(re, im, out=(ore, oim))

@@ -156,7 +156,11 @@ PDSP_API int pdsp_plan_window_f64(pdsp_plan *plan, int type, const double **wind
 PDSP_API int pdsp_fft_forward_real_f32(const pdsp_plan *plan, long long batch,
                                        const float *re_in, float *re_out, float *im_out,
                                        pdsp_stream stream);
-/* Radix2Fft.forwardComplex, src/core/fft.ts:81-83. */
+/* Radix2Fft.forwardComplex, src/core/fft.ts:81-83.
+ * Where the four planes lie matters on this card (8-14 % at N = 4096): inside one large allocation the address space
+ * behaves as regions of 32 GiB, and the launch is fastest -- and repeatable -- with both input planes in one region
+ * and each output plane in a region of its own, e.g. offsets 0 / plane / 40 GiB / 80 GiB of one allocation
+ * (pragma_dsp_amd.batch.BatchedFft.alloc_planes does exactly that). */
 PDSP_API int pdsp_fft_forward_complex_f32(const pdsp_plan *plan, long long batch,
                                           const float *re_in, const float *im_in,
                                           float *re_out, float *im_out, pdsp_stream stream);

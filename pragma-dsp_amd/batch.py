@@ -69,6 +69,7 @@ class BatchedFft:
         check(lib.pdsp_plan_create(self.size, self.device.index, C.byref(handle)))
         self._h = handle
         self._windows = {}
+        self.arena = None  # the allocation behind the planes of the last alloc_planes() call, if any
 
     def close(self):
         """Destroys the native plan now (also done when the object is collected).  For a size beyond the single-pass
@@ -123,6 +124,45 @@ class BatchedFft:
             check(getattr(lib, "pdsp_plan_window_" + self._sfx)(self._h, _capi.WINDOW_TYPES[kind], C.byref(out)))
             p = self._windows[kind] = out.value
         return PlanWindow(self, kind, p)
+
+    # -- plane layout ----------------------------------------------------------
+    # Where the four planes of a transform lie in HBM decides 8-14 % of the N = 4096 kernel's rate (DESIGN section 5,
+    # "What the spread of configs[2] is made of"): inside one large allocation the card's address space behaves as
+    # regions of 32 GiB, and the launch runs at its upper plateau (83-85 % of the HBM roofline against 76 % for four
+    # planes back to back, 71-73 % for unlucky ones) when the two INPUT planes share a region and each OUTPUT plane
+    # has a region of its own.  Offsets of 0 | plane | 40 GiB | 80 GiB put the outputs one and two regions beyond the
+    # inputs whatever the phase of the allocation against the region grid (40 - plane > 32 > 40 - 32; 80 likewise).
+    ARENA_OUT_GIB = (40, 80)
+
+    def alloc_planes(self, batch: int, real_input: bool = False):
+        """(re_in, im_in | None, re_out, im_out) for `batch` rows, carved out of ONE allocation of 80 GiB + one plane
+        with the layout above -- the card has 288 GB; the gaps stay usable through `.arena` (a uint8 tensor) -- or,
+        when that much memory is not free or a plane exceeds 8 GiB, four plain allocations (`.arena` is None).
+        The tensors keep the allocation alive."""
+        rows, n = int(batch), self.size
+        esize = 4 if self.dtype == torch.float32 else 8
+        plane = rows * n * esize
+        gib = 1 << 30
+        arena = None
+        if 0 < plane <= 8 * gib:
+            try:
+                free, _total = torch.cuda.mem_get_info(self.device)
+                need = self.ARENA_OUT_GIB[1] * gib + plane
+                if free >= need + 4 * gib:
+                    arena = torch.empty(need, dtype=torch.uint8, device=self.device)
+            except RuntimeError:
+                arena = None
+        self.arena = arena
+        if arena is None:
+            mk = lambda: torch.empty((rows, n), dtype=self.dtype, device=self.device)  # noqa: E731
+            return mk(), (None if real_input else mk()), mk(), mk()
+        pad = (plane + 255) & ~255  # the second input plane starts on a 256-byte boundary
+
+        def view(off):
+            return arena[off:off + plane].view(self.dtype).view(rows, n)
+
+        return (view(0), (None if real_input else view(pad)), view(self.ARENA_OUT_GIB[0] * gib),
+                view(self.ARENA_OUT_GIB[1] * gib))
 
     # -- transforms ------------------------------------------------------------
     def forward(self, re: torch.Tensor, im: torch.Tensor | None = None, out=None):
