@@ -87,6 +87,9 @@ def _load() -> C.CDLL:
         "pdsp_plan_size": ([vp], ll),
         "pdsp_plan_cache_clear": ([], i32),
         "pdsp_plan_device": ([vp], i32),
+        "pdsp_planes_alloc": ([vp, ll, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                               C.POINTER(C.c_ulonglong)], i32),
+        "pdsp_planes_free": ([vp], i32),
         "pdsp_fft_forward_real_f32": ([vp, ll, vp, vp, vp, vp], i32),
         "pdsp_fft_forward_complex_f32": ([vp, ll, vp, vp, vp, vp, vp], i32),
         "pdsp_fft_inverse_f32": ([vp, ll, vp, vp, vp, vp, vp], i32),

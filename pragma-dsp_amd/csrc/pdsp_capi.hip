@@ -1146,6 +1146,75 @@ int pdsp_plan_destroy(pdsp_plan *plan) {
 long long pdsp_plan_size(const pdsp_plan *plan) { return plan ? plan->n : 0; }
 int pdsp_plan_device(const pdsp_plan *plan) { return plan ? plan->device : -1; }
 
+/* ---- plane layout ------------------------------------------------------------ */
+
+struct pdsp_arena {
+  int device = -1;
+  void *parts[4] = {nullptr, nullptr, nullptr, nullptr};  // one entry (the arena) or up to four plain allocations
+};
+
+int pdsp_planes_alloc(const pdsp_plan *plan, long long batch, int scalar_bytes, int real_input, void **re_in,
+                      void **im_in, void **re_out, void **im_out, pdsp_arena **arena, unsigned long long *arena_bytes) {
+  if (!plan) return fail(PDSP_ERR_BAD_ARG, "plan is null");
+  if (!re_in || !im_in || !re_out || !im_out || !arena) return fail(PDSP_ERR_BAD_ARG, "null output");
+  if (batch <= 0) return fail(PDSP_ERR_BAD_ARG, "batch must be > 0, got %lld", batch);
+  if (scalar_bytes != 4 && scalar_bytes != 8) return fail(PDSP_ERR_BAD_ARG, "scalar_bytes must be 4 or 8, got %d", scalar_bytes);
+  *re_in = *im_in = *re_out = *im_out = nullptr;
+  *arena = nullptr;
+  if (arena_bytes) *arena_bytes = 0;
+  DeviceGuard g(plan->device);
+  PDSP_HIP_TRY(g.err);
+  const size_t gib = (size_t)1 << 30;
+  const size_t plane = (size_t)batch * (size_t)plan->n * (size_t)scalar_bytes;
+  pdsp_arena *a = new (std::nothrow) pdsp_arena();
+  if (!a) return fail(PDSP_ERR_BAD_ARG, "out of host memory");
+  a->device = plan->device;
+  if (plane <= 8 * gib) {
+    size_t free_b = 0, total_b = 0;
+    const size_t need = 80 * gib + plane;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= need + 4 * gib) {
+      void *base = nullptr;
+      if (hipMalloc(&base, need) == hipSuccess) {
+        a->parts[0] = base;
+        char *b = (char *)base;
+        *re_in = b;
+        *im_in = real_input ? nullptr : b + ((plane + 255) & ~(size_t)255);
+        *re_out = b + 40 * gib;
+        *im_out = b + 80 * gib;
+        *arena = a;
+        if (arena_bytes) *arena_bytes = (unsigned long long)need;
+        return PDSP_OK;
+      }
+      (void)hipGetLastError();
+    }
+  }
+  // no room for the layout: four plain allocations
+  void **outs[4] = {re_in, im_in, re_out, im_out};
+  for (int i = 0; i < 4; ++i) {
+    if (i == 1 && real_input) continue;
+    const hipError_t e = hipMalloc(&a->parts[i], plane);
+    if (e != hipSuccess) {
+      for (void *p : a->parts)
+        if (p) (void)hipFree(p);
+      delete a;
+      *re_in = *im_in = *re_out = *im_out = nullptr;
+      return fail(PDSP_ERR_DEVICE, "HIP error %d (%s) at hipMalloc of a plane of %zu bytes", (int)e, hipGetErrorString(e), plane);
+    }
+    *outs[i] = a->parts[i];
+  }
+  *arena = a;
+  return PDSP_OK;
+}
+
+int pdsp_planes_free(pdsp_arena *arena) {
+  if (!arena) return PDSP_OK;
+  DeviceGuard g(arena->device);
+  for (void *p : arena->parts)
+    if (p) (void)hipFree(p);
+  delete arena;
+  return PDSP_OK;
+}
+
 /* ---- device-pointer transforms --------------------------------------------- */
 
 #define PDSP_DEFINE_TRANSFORMS(SUFFIX, T)                                                                          \

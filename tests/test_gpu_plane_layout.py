@@ -47,3 +47,60 @@ def test_alloc_planes_layout_and_parity(oracle_mod, dtype, tol):
     del re, im, oim, r2, o2, p2
     torch.cuda.empty_cache()
     assert torch.isfinite(keep).all()
+
+
+class _DevView:
+    """A raw device pointer as a torch tensor (no copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+@pytest.mark.parametrize("scalar_bytes,tol", [(4, 1e-5), (8, 1e-12)])
+def test_c_abi_planes_alloc_layout_and_parity(oracle_mod, scalar_bytes, tol):
+    """pdsp_planes_alloc / pdsp_planes_free: the same layout through the C ABI (what a C or JS caller of the
+    device-pointer family uses), a transform through the returned planes against the oracle, argument errors."""
+    import ctypes as C
+    from pragma_dsp_amd import _capi
+    lib, vp = _capi.lib, C.c_void_p
+    n, rows = 2048, 40
+    plan = vp()
+    _capi.check(lib.pdsp_plan_create(n, -1, C.byref(plan)))
+    try:
+        ptrs = [vp() for _ in range(4)]
+        arena, nbytes = vp(), C.c_ulonglong(0)
+        _capi.check(lib.pdsp_planes_alloc(plan, rows, scalar_bytes, 0, *[C.byref(p) for p in ptrs], C.byref(arena), C.byref(nbytes)))
+        plane = rows * n * scalar_bytes
+        base = ptrs[0].value
+        if nbytes.value:  # the layout: one allocation of 80 GiB + a plane
+            assert nbytes.value == 80 * GIB + plane
+            assert ptrs[1].value == base + ((plane + 255) & ~255)
+            assert ptrs[2].value == base + 40 * GIB and ptrs[3].value == base + 80 * GIB
+        else:
+            assert len({p.value for p in ptrs}) == 4
+        dt, ts = (torch.float32, "<f4") if scalar_bytes == 4 else (torch.float64, "<f8")
+        re, im, ore, oim = (torch.as_tensor(_DevView(p.value, (rows, n), ts), device="cuda:0") for p in ptrs)
+        rng = np.random.default_rng(3)
+        x, y = rng.standard_normal((rows, n)), rng.standard_normal((rows, n))
+        re.copy_(torch.from_numpy(x).to(dt))
+        im.copy_(torch.from_numpy(y).to(dt))
+        torch.cuda.synchronize()
+        fwd = lib.pdsp_fft_forward_complex_f32 if scalar_bytes == 4 else lib.pdsp_fft_forward_complex_f64
+        _capi.check(fwd(plan, rows, ptrs[0], ptrs[1], ptrs[2], ptrs[3], None))
+        torch.cuda.synchronize()
+        wre, wim = oracle_mod.Plan(n).forward_complex(re.cpu().numpy().astype(np.float64), im.cpu().numpy().astype(np.float64))
+        got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy().astype(np.float64)
+        want = wre + 1j * wim
+        assert (np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)).max() <= tol
+        del re, im, ore, oim
+        assert lib.pdsp_planes_free(arena) == 0
+        # real input: no imaginary input plane
+        _capi.check(lib.pdsp_planes_alloc(plan, rows, scalar_bytes, 1, *[C.byref(p) for p in ptrs], C.byref(arena), None))
+        assert ptrs[1].value is None and ptrs[0].value and ptrs[2].value and ptrs[3].value
+        assert lib.pdsp_planes_free(arena) == 0 and lib.pdsp_planes_free(None) == 0
+        # argument errors
+        assert lib.pdsp_planes_alloc(plan, 0, 4, 0, *[C.byref(p) for p in ptrs], C.byref(arena), None) == _capi.ERR_BAD_ARG
+        assert lib.pdsp_planes_alloc(plan, rows, 2, 0, *[C.byref(p) for p in ptrs], C.byref(arena), None) == _capi.ERR_BAD_ARG
+        assert lib.pdsp_planes_alloc(None, rows, 4, 0, *[C.byref(p) for p in ptrs], C.byref(arena), None) == _capi.ERR_BAD_ARG
+    finally:
+        lib.pdsp_plan_destroy(plan)
