@@ -157,7 +157,8 @@ PDSP_API int pdsp_plan_window_f64(pdsp_plan *plan, int type, const double **wind
  * lottery for four separate allocations -- with both INPUT planes in one region and each OUTPUT plane in a region
  * of its own.  One allocation of 80 GiB + a plane: re_in at 0, im_in right behind it, re_out
  * 40 GiB in, im_out 80 GiB in (any phase of the allocation against the region grid then puts the outputs one and two
- * regions beyond the inputs).  When that much memory is not free, or a plane exceeds 8 GiB: four plain allocations.
+ * regions beyond the inputs).  When that much memory is not free, or a plane is below 256 MiB (nothing to gain) or
+ * above 8 GiB: four plain allocations.
  *   scalar_bytes  4 (float planes) or 8 (double planes); each plane holds batch * N scalars
  *   real_input    non-zero: no imaginary input plane (*im_in = NULL)
  *   *arena        opaque handle for pdsp_planes_free (which frees all four planes); *arena_bytes (may be NULL)

@@ -137,14 +137,14 @@ class BatchedFft:
     def alloc_planes(self, batch: int, real_input: bool = False):
         """(re_in, im_in | None, re_out, im_out) for `batch` rows, carved out of ONE allocation of 80 GiB + one plane
         with the layout above -- the card has 288 GB; the gaps stay usable through `.arena` (a uint8 tensor) -- or,
-        when that much memory is not free or a plane exceeds 8 GiB, four plain allocations (`.arena` is None).
+        when that much memory is not free or a plane is below 256 MiB or above 8 GiB, four plain allocations (`.arena` is None).
         The tensors keep the allocation alive."""
         rows, n = int(batch), self.size
         esize = 4 if self.dtype == torch.float32 else 8
         plane = rows * n * esize
         gib = 1 << 30
         arena = None
-        if 0 < plane <= 8 * gib:
+        if (256 << 20) <= plane <= 8 * gib:  # planes below 256 MiB: nothing to gain, plain allocations
             try:
                 free, _total = torch.cuda.mem_get_info(self.device)
                 need = self.ARENA_OUT_GIB[1] * gib + plane

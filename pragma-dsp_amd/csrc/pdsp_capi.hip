@@ -1169,7 +1169,7 @@ int pdsp_planes_alloc(const pdsp_plan *plan, long long batch, int scalar_bytes, 
   pdsp_arena *a = new (std::nothrow) pdsp_arena();
   if (!a) return fail(PDSP_ERR_BAD_ARG, "out of host memory");
   a->device = plan->device;
-  if (plane <= 8 * gib) {
+  if (plane >= ((size_t)256 << 20) && plane <= 8 * gib) {  // smaller planes have nothing to gain: plain allocations
     size_t free_b = 0, total_b = 0;
     const size_t need = 80 * gib + plane;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= need + 4 * gib) {

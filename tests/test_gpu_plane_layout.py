@@ -23,8 +23,11 @@ def _give_the_arena_back():
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float64, 1e-12)])
 def test_alloc_planes_layout_and_parity(oracle_mod, dtype, tol):
     from pragma_dsp_amd.batch import BatchedFft
-    n, rows = 1024, 96
+    n, rows = 4096, 16384 if dtype == torch.float32 else 8192   # 256-MiB planes: the smallest that get the layout
     plan = BatchedFft(n, "cuda:0", dtype=dtype)
+    small = plan.alloc_planes(64)                                 # small planes: plain allocations
+    assert plan.arena is None and len({t.data_ptr() for t in small}) == 4
+    del small
     re, im, ore, oim = plan.alloc_planes(rows)
     esize = 4 if dtype == torch.float32 else 8
     plane = rows * n * esize
@@ -38,19 +41,18 @@ def test_alloc_planes_layout_and_parity(oracle_mod, dtype, tol):
         assert plan.arena.numel() == 80 * GIB + plane
     else:  # a card without 84 GiB free: plain allocations, same contract
         assert len({t.data_ptr() for t in (re, im, ore, oim)}) == 4
-    rng = np.random.default_rng(11)
-    x, y = rng.standard_normal((rows, n)), rng.standard_normal((rows, n))
-    re.copy_(torch.from_numpy(x).to(dtype))
-    im.copy_(torch.from_numpy(y).to(dtype))
+    re.normal_()
+    im.normal_()
     plan.forward(re, im, out=(ore, oim))
     torch.cuda.synchronize()
-    wre, wim = oracle_mod.Plan(n).forward_complex(re.cpu().numpy().astype(np.float64), im.cpu().numpy().astype(np.float64))
-    got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy().astype(np.float64)
+    sel = torch.tensor([0, 1, rows // 2, rows - 1], device=re.device)   # first, middle and last rows of the planes
+    wre, wim = oracle_mod.Plan(n).forward_complex(re[sel].cpu().numpy().astype(np.float64), im[sel].cpu().numpy().astype(np.float64))
+    got = ore[sel].cpu().numpy().astype(np.float64) + 1j * oim[sel].cpu().numpy().astype(np.float64)
     want = wre + 1j * wim
     assert (np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)).max() <= tol
     # real input: no imaginary input plane
-    r2, none, o2, p2 = plan.alloc_planes(rows, real_input=True)
-    assert none is None and r2.shape == o2.shape == p2.shape == (rows, n)
+    r2, none, o2, p2 = plan.alloc_planes(64, real_input=True)
+    assert none is None and r2.shape == o2.shape == p2.shape == (64, n)
     # the planes keep their allocation alive after the plan has let go of it
     keep = ore
     plan.arena = None
@@ -73,7 +75,7 @@ def test_c_abi_planes_alloc_layout_and_parity(oracle_mod, scalar_bytes, tol):
     import ctypes as C
     from pragma_dsp_amd import _capi
     lib, vp = _capi.lib, C.c_void_p
-    n, rows = 2048, 40
+    n, rows = 4096, (16384 if scalar_bytes == 4 else 8192)   # 256-MiB planes: the smallest that get the layout
     plan = vp()
     _capi.check(lib.pdsp_plan_create(n, -1, C.byref(plan)))
     try:
@@ -90,23 +92,24 @@ def test_c_abi_planes_alloc_layout_and_parity(oracle_mod, scalar_bytes, tol):
             assert len({p.value for p in ptrs}) == 4
         dt, ts = (torch.float32, "<f4") if scalar_bytes == 4 else (torch.float64, "<f8")
         re, im, ore, oim = (torch.as_tensor(_DevView(p.value, (rows, n), ts), device="cuda:0") for p in ptrs)
-        rng = np.random.default_rng(3)
-        x, y = rng.standard_normal((rows, n)), rng.standard_normal((rows, n))
-        re.copy_(torch.from_numpy(x).to(dt))
-        im.copy_(torch.from_numpy(y).to(dt))
+        re.normal_()
+        im.normal_()
         torch.cuda.synchronize()
         fwd = lib.pdsp_fft_forward_complex_f32 if scalar_bytes == 4 else lib.pdsp_fft_forward_complex_f64
         _capi.check(fwd(plan, rows, ptrs[0], ptrs[1], ptrs[2], ptrs[3], None))
         torch.cuda.synchronize()
-        wre, wim = oracle_mod.Plan(n).forward_complex(re.cpu().numpy().astype(np.float64), im.cpu().numpy().astype(np.float64))
-        got = ore.cpu().numpy().astype(np.float64) + 1j * oim.cpu().numpy().astype(np.float64)
+        sel = torch.tensor([0, 1, rows // 2, rows - 1], device=re.device)
+        wre, wim = oracle_mod.Plan(n).forward_complex(re[sel].cpu().numpy().astype(np.float64), im[sel].cpu().numpy().astype(np.float64))
+        got = ore[sel].cpu().numpy().astype(np.float64) + 1j * oim[sel].cpu().numpy().astype(np.float64)
         want = wre + 1j * wim
         assert (np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)).max() <= tol
         del re, im, ore, oim
         assert lib.pdsp_planes_free(arena) == 0
         # real input: no imaginary input plane
-        _capi.check(lib.pdsp_planes_alloc(plan, rows, scalar_bytes, 1, *[C.byref(p) for p in ptrs], C.byref(arena), None))
+        small = C.c_ulonglong(1)
+        _capi.check(lib.pdsp_planes_alloc(plan, 32, scalar_bytes, 1, *[C.byref(p) for p in ptrs], C.byref(arena), C.byref(small)))
         assert ptrs[1].value is None and ptrs[0].value and ptrs[2].value and ptrs[3].value
+        assert small.value == 0   # small planes: plain allocations
         assert lib.pdsp_planes_free(arena) == 0 and lib.pdsp_planes_free(None) == 0
         # argument errors
         assert lib.pdsp_planes_alloc(plan, 0, 4, 0, *[C.byref(p) for p in ptrs], C.byref(arena), None) == _capi.ERR_BAD_ARG
